@@ -1,0 +1,289 @@
+"""ctypes binding of libimageclust_hip.so (the C-ABI declared in include/imageclust.h).
+
+This module is plumbing only: it loads the in-tree shared object built by `__graft_entry__.build()` (or
+`make -C imageclust_amd/csrc`) and fails loudly when it is missing -- there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libimageclust_hip.so")
+
+ICL_OK = 0
+ICL_ERR_ARG, ICL_ERR_CONSTRAINT, ICL_ERR_HIP, ICL_ERR_NOMODEL, ICL_ERR_IO, ICL_ERR_UNSUPPORTED, ICL_ERR_OVERSIZE, ICL_ERR_NOMEM = range(1, 9)
+HEAD_POOLED, HEAD_DENSE0 = 2048, 1000
+PREC_FP32, PREC_BF16 = 0, 1
+UPDATE_EXACT, UPDATE_LW = 0, 1
+SYNTH_NOISE, SYNTH_STRUCTURED = 0, 1
+K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER = range(6)
+K_NAMES = ["conv_igemm", "ward_dist_exact", "dist_mfma", "row_argmin", "ward_update_exact", "embed_other"]
+IMG_BYTES = 224 * 224 * 3
+
+# every symbol include/imageclust.h declares: (name, restype, argtypes)
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+_pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+_pd = C.POINTER(C.c_double)
+SYMBOLS = [
+    ("icl_create", _int, [_int, C.POINTER(_vp)]),
+    ("icl_destroy", None, [_vp]),
+    ("icl_last_error", C.c_char_p, [_vp]),
+    ("icl_stream", _vp, [_vp]),
+    ("icl_sync", _int, [_vp]),
+    ("icl_device_info", _int, [_vp, C.c_char_p, _int, C.POINTER(_int), _pi64]),
+    ("icl_dev_malloc", _int, [_vp, _i64, C.POINTER(_vp)]),
+    ("icl_dev_free", _int, [_vp, _vp]),
+    ("icl_memcpy_h2d", _int, [_vp, _vp, _vp, _i64]),
+    ("icl_memcpy_d2h", _int, [_vp, _vp, _vp, _i64]),
+    ("icl_model_load_onnx", _int, [_vp, C.c_char_p]),
+    ("icl_model_load_blob", _int, [_vp, _vp, _i64]),
+    ("icl_model_load_synthetic", _int, [_vp, C.c_uint64]),
+    ("icl_synthetic_blob_bytes", _i64, []),
+    ("icl_synthetic_blob", _int, [C.c_uint64, _vp, _i64]),
+    ("icl_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
+    ("icl_embed_u8_dev", _int, [_vp, _vp, _i64, _int, _int, _vp]),
+    ("icl_embed_file", _int, [_vp, C.c_char_p, _int, _vp]),
+    ("icl_preprocess_u8", _int, [_vp, _vp]),
+    ("icl_set_batch", _int, [_vp, _int]),
+    ("icl_calc_optimal_clusters", _int, [_i64, _i64, _i64, _pi64]),
+    ("icl_ward_distance_matrix", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
+    ("icl_ward_distance_matrix_dev", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
+    ("icl_merge_centroid", _int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp]),
+    ("icl_find_closest", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
+    ("icl_find_closest_dev", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
+    ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_cluster_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_last_merges", _i64, [_vp, _vp, _i64]),
+    ("icl_distance_mfma_dev", _int, [_vp, _vp, _i64, _i32, _vp, _i64]),
+    ("icl_synth_images", _int, [C.c_uint64, _i64, _i64, _int, _vp]),
+    ("icl_synth_images_dev", _int, [_vp, C.c_uint64, _i64, _i64, _int, _vp]),
+    ("icl_prof_enable", _int, [_vp, _int]),
+    ("icl_prof_reset", _int, [_vp]),
+    ("icl_prof_query", _int, [_vp, _int, _pd, _pi64, _pd, _pd]),
+    ("icl_last_stage_ms", _int, [_vp, _pd, _pd, _pd]),
+    ("icl_version", C.c_char_p, []),
+]
+
+_lib = None
+
+
+class ICLError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("icl error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load the HIP engine.  Raises (never falls back) if the shared object is absent or lacks a symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); imageclust_amd has no CPU fallback" % SO_PATH)
+    try:
+        # Share ONE HIP runtime with PyTorch when both live in a process: torch bundles its own libamdhip64
+        # (same soname), so import it first and let the dynamic loader reuse that copy.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(SO_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(ctx_handle, rc):
+    if rc != ICL_OK:
+        msg = load().icl_last_error(ctx_handle)
+        raise ICLError(rc, msg.decode() if msg else "")
+
+
+class Context:
+    """One GPU, one stream (icl_ctx)."""
+
+    def __init__(self, device=0):
+        L = load()
+        h = _vp()
+        rc = L.icl_create(device, C.byref(h))
+        if rc != ICL_OK:
+            msg = L.icl_last_error(None)
+            raise ICLError(rc, msg.decode() if msg else "")
+        self.h = h
+        self.L = L
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.icl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- memory ---------------------------------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = _vp()
+        check(self.h, self.L.icl_dev_malloc(self.h, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def free(self, p):
+        check(self.h, self.L.icl_dev_free(self.h, _vp(p)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.h, self.L.icl_memcpy_h2d(self.h, _vp(dptr), arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self.h, self.L.icl_memcpy_d2h(self.h, arr.ctypes.data, _vp(dptr), arr.nbytes))
+
+    def sync(self):
+        check(self.h, self.L.icl_sync(self.h))
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        ncu = _int()
+        hbm = _i64()
+        check(self.h, self.L.icl_device_info(self.h, buf, 256, C.byref(ncu), C.byref(hbm)))
+        return buf.value.decode(), ncu.value, hbm.value
+
+    # -- profiling ------------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self.h, self.L.icl_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.h, self.L.icl_prof_reset(self.h))
+
+    def prof_query(self, k):
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        n = _i64()
+        check(self.h, self.L.icl_prof_query(self.h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+    def last_stage_ms(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(self.h, self.L.icl_last_stage_ms(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(embed_ms=a.value, dist_ms=b.value, merge_ms=c.value)
+
+    # -- model / embed --------------------------------------------------------------------------------
+    def load_synthetic(self, seed=1):
+        check(self.h, self.L.icl_model_load_synthetic(self.h, seed))
+
+    def load_blob(self, blob):
+        buf = np.frombuffer(blob, np.uint8)
+        check(self.h, self.L.icl_model_load_blob(self.h, buf.ctypes.data, buf.nbytes))
+
+    def load_onnx(self, path):
+        check(self.h, self.L.icl_model_load_onnx(self.h, os.fsencode(path)))
+
+    def set_batch(self, b):
+        check(self.h, self.L.icl_set_batch(self.h, b))
+
+    def embed_u8(self, imgs, head=HEAD_POOLED, prec=PREC_FP32):
+        imgs = np.ascontiguousarray(imgs, np.uint8).reshape(-1, IMG_BYTES)
+        n = imgs.shape[0]
+        out = np.empty((n, head), np.float32)
+        check(self.h, self.L.icl_embed_u8(self.h, imgs.ctypes.data, n, head, prec, out.ctypes.data))
+        return out
+
+    def embed_u8_dev(self, d_imgs, n, d_out, head=HEAD_POOLED, prec=PREC_BF16):
+        check(self.h, self.L.icl_embed_u8_dev(self.h, _vp(d_imgs), n, head, prec, _vp(d_out)))
+
+    def embed_file(self, path, head=HEAD_DENSE0):
+        out = np.empty(head, np.float32)
+        check(self.h, self.L.icl_embed_file(self.h, os.fsencode(path), head, out.ctypes.data))
+        return out
+
+    def synth_images_dev(self, seed, first, n, mode, d_out):
+        check(self.h, self.L.icl_synth_images_dev(self.h, seed, first, n, mode, _vp(d_out)))
+
+    # -- Ward -----------------------------------------------------------------------------------------
+    def ward_distance_matrix(self, centroids, sizes=None):
+        Cm = np.ascontiguousarray(centroids, np.float32)
+        n, d = Cm.shape
+        D = np.zeros((n, n), np.float32)
+        sp = None
+        if sizes is not None:
+            sizes = np.ascontiguousarray(sizes, np.int32)
+            sp = sizes.ctypes.data
+        check(self.h, self.L.icl_ward_distance_matrix(self.h, Cm.ctypes.data, sp, n, d, D.ctypes.data, n))
+        return D
+
+    def merge_centroid(self, ca, sa, cb, sb):
+        ca = np.ascontiguousarray(ca, np.float32)
+        cb = np.ascontiguousarray(cb, np.float32)
+        out = np.empty_like(ca)
+        check(self.h, self.L.icl_merge_centroid(self.h, ca.ctypes.data, int(sa), cb.ctypes.data, int(sb), ca.shape[0],
+                                                out.ctypes.data))
+        return out
+
+    def find_closest(self, D):
+        D = np.ascontiguousarray(D, np.float32)
+        n = D.shape[0]
+        i, j = _i64(), _i64()
+        check(self.h, self.L.icl_find_closest(self.h, D.ctypes.data if n else None, n, D.shape[1] if n else 0,
+                                              C.byref(i), C.byref(j)))
+        return i.value, j.value
+
+    def cluster(self, E, min_size, max_size, update=UPDATE_EXACT):
+        """-> (cluster_id[n], member_rank[n], n_clusters); raises ICLError(ICL_ERR_CONSTRAINT) for (nil,false)."""
+        E = np.ascontiguousarray(E, np.float32)
+        n, d = E.shape
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        check(self.h, self.L.icl_cluster(self.h, E.ctypes.data if E.size else None, n, d, min_size, max_size, update,
+                                         cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
+        return cid[:n], rank[:n], nc.value
+
+    def cluster_dev(self, d_E, n, d, min_size, max_size, update=UPDATE_EXACT):
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        check(self.h, self.L.icl_cluster_dev(self.h, _vp(d_E), n, d, min_size, max_size, update, cid.ctypes.data,
+                                             rank.ctypes.data, C.byref(nc)))
+        return cid[:n], rank[:n], nc.value
+
+    def last_merges(self):
+        n = self.L.icl_last_merges(self.h, None, 0)
+        out = np.zeros((max(n, 1), 2), np.int32)
+        self.L.icl_last_merges(self.h, out.ctypes.data, n)
+        return out[:n]
+
+
+def calc_optimal_clusters(total, min_size, max_size):
+    k = _i64()
+    rc = load().icl_calc_optimal_clusters(total, min_size, max_size, C.byref(k))
+    return (k.value, None) if rc == ICL_OK else (0, rc)
+
+
+def synth_images(seed, first, n, mode=SYNTH_NOISE):
+    out = np.empty((n, 224, 224, 3), np.uint8)
+    rc = load().icl_synth_images(seed, first, n, mode, out.ctypes.data)
+    if rc:
+        raise ICLError(rc, "icl_synth_images")
+    return out
+
+
+def synthetic_blob(seed=1):
+    L = load()
+    nb = L.icl_synthetic_blob_bytes()
+    buf = np.empty(nb, np.uint8)
+    rc = L.icl_synthetic_blob(seed, buf.ctypes.data, nb)
+    if rc:
+        raise ICLError(rc, "icl_synthetic_blob")
+    return buf

@@ -1,0 +1,140 @@
+"""Host-side mirror of /root/reference/internal/clustering/clustering.go over the HIP engine.
+
+Same exported names, argument meaning and error behaviour as the Go package, so the parity tests read like
+tests of the reference.  Every arithmetic result comes from libimageclust_hip.so through its C-ABI
+(include/imageclust.h); the functions that only re-arrange lists (NewCluster, RemoveClusters,
+RemoveRowsAndColumns) are plain data-structure code exactly as in the Go file.  There is no CPU fallback:
+without the built library (or without a gfx950 device) these functions raise.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_default_ctx: Optional[_lib.Context] = None
+
+
+def default_context() -> _lib.Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = _lib.Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx: Optional[_lib.Context]):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+@dataclass
+class Cluster:
+    """clustering.go:11-15"""
+    Indices: List[int] = field(default_factory=list)
+    Size: int = 0
+    Centroid: np.ndarray = None
+
+
+def NewCluster(index: int, embedding) -> Cluster:
+    """clustering.go:18-26: singleton with a COPY of the embedding."""
+    return Cluster(Indices=[int(index)], Size=1, Centroid=np.array(embedding, dtype=np.float32, copy=True))
+
+
+def MergeClusters(a: Cluster, b: Cluster, ctx: Optional[_lib.Context] = None) -> Cluster:
+    """clustering.go:29-47: members a++b, centroid (float(sa)*Ca + float(sb)*Cb)/float(sa+sb) on the GPU."""
+    ctx = ctx or default_context()
+    return Cluster(Indices=list(a.Indices) + list(b.Indices), Size=a.Size + b.Size,
+                   Centroid=ctx.merge_centroid(a.Centroid, a.Size, b.Centroid, b.Size))
+
+
+def RemoveClusters(clusters: List[Cluster], i: int, j: int) -> List[Cluster]:
+    """clustering.go:51-58: order-preserving removal of positions i and j."""
+    if i > j:
+        i, j = j, i
+    return clusters[:i] + clusters[i + 1:j] + clusters[j + 1:]
+
+
+def ComputeInitialDistanceMatrix(clusters: List[Cluster], ctx: Optional[_lib.Context] = None) -> np.ndarray:
+    """clustering.go:61-73 -> n x n fp32, symmetric, zero diagonal (exact Ward tile kernel)."""
+    ctx = ctx or default_context()
+    n = len(clusters)
+    if n == 0:
+        return np.zeros((0, 0), np.float32)
+    C = np.stack([np.asarray(c.Centroid, np.float32) for c in clusters])
+    sizes = np.array([c.Size for c in clusters], np.int32)
+    return ctx.ward_distance_matrix(C, sizes)
+
+
+def RemoveRowsAndColumns(matrix: np.ndarray, i: int, j: int) -> np.ndarray:
+    """clustering.go:100-116"""
+    keep = [k for k in range(matrix.shape[0]) if k != i and k != j]
+    return matrix[np.ix_(keep, keep)]
+
+
+def WardDistance(a: Cluster, b: Cluster, ctx: Optional[_lib.Context] = None) -> np.float32:
+    """clustering.go:136-145 for one pair (a 2x2 call of the distance tile)."""
+    return ComputeInitialDistanceMatrix([a, b], ctx)[1, 0]
+
+
+def UpdateDistanceMatrix(distanceMatrix: np.ndarray, clusters: List[Cluster], newCluster: Cluster, removedIdx1: int,
+                         removedIdx2: int, ctx: Optional[_lib.Context] = None) -> np.ndarray:
+    """clustering.go:76-96: drop two rows/columns, append the new cluster's row/column computed from centroids.
+    `clusters` is the list AFTER removal and append (newCluster last), as at clustering.go:244."""
+    ctx = ctx or default_context()
+    D = RemoveRowsAndColumns(np.asarray(distanceMatrix, np.float32), removedIdx1, removedIdx2)
+    n = len(clusters)
+    full = ComputeInitialDistanceMatrix(clusters, ctx)
+    out = np.zeros((n, n), np.float32)
+    out[: n - 1, : n - 1] = D
+    out[n - 1, :] = full[n - 1, :]
+    out[:, n - 1] = full[:, n - 1]
+    return out
+
+
+def FindClosestClusters(distanceMatrix, ctx: Optional[_lib.Context] = None) -> Tuple[int, int]:
+    """clustering.go:119-133 -> (i, j) with i > j, or (-1, -1)."""
+    ctx = ctx or default_context()
+    D = np.asarray(distanceMatrix, np.float32)
+    if D.ndim != 2 or D.shape[0] == 0:
+        return -1, -1
+    return ctx.find_closest(D)
+
+
+def CalculateOptimalClusters(totalItems: int, minSize: int, maxSize: int):
+    """clustering.go:168-186 -> (nClusters, err) with err None on success."""
+    k, rc = _lib.calc_optimal_clusters(totalItems, minSize, maxSize)
+    if rc is not None:
+        if totalItems < minSize:
+            return 0, "total items (%d) less than minimum cluster size (%d)" % (totalItems, minSize)
+        return 0, ("cannot satisfy cluster size constraints with total items (%d), minSize (%d), and maxSize (%d)"
+                   % (totalItems, minSize, maxSize))
+    return k, None
+
+
+def PerformClusteringWithConstraints(embeddings, productReferenceIDs: List[str], minSize: int, maxSize: int,
+                                     ctx: Optional[_lib.Context] = None,
+                                     update: int = _lib.UPDATE_EXACT) -> Tuple[Optional[Dict[int, List[str]]], bool]:
+    """clustering.go:198-284 -> (map cluster id -> member ids, ok).  (None, False) on impossible constraints."""
+    ctx = ctx or default_context()
+    E = np.asarray(embeddings, np.float32)
+    if E.ndim != 2:
+        E = E.reshape(len(embeddings), -1)
+    try:
+        cid, rank, _ = ctx.cluster(E, minSize, maxSize, update)
+    except _lib.ICLError as e:
+        if e.code == _lib.ICL_ERR_CONSTRAINT:
+            return None, False
+        raise
+    return clusters_as_map(cid, rank, productReferenceIDs), True
+
+
+def clusters_as_map(cluster_id, member_rank, ids) -> Dict[int, List[str]]:
+    """Canonical (cluster_id, member_rank) -> map[int][]string of clustering.go:265-280."""
+    out: Dict[int, List[str]] = {}
+    order = np.lexsort((member_rank, cluster_id))
+    for i in order:
+        c = int(cluster_id[i])
+        if c >= 0:
+            out.setdefault(c, []).append(ids[i])
+    return out

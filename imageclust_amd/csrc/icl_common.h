@@ -1,0 +1,119 @@
+// icl_common.h -- internal definitions shared by the translation units of libimageclust_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/icl_model_format.h"
+#include "../../include/imageclust.h"
+
+#define ICL_MAXF 3.40282346638528859811704183484516925e+38f /* math.MaxFloat32 */
+
+struct icl_prof_slot {
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+struct icl_pending_event {
+    hipEvent_t a, b;
+    int kclass;
+};
+
+struct icl_model;  // resnet.hip
+struct icl_ward_ws; // ward.hip
+
+struct icl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    hipDeviceProp_t prop;
+    int batch = 256;
+    // profiling
+    bool prof_on = false;
+    icl_prof_slot prof[ICL_K_NCLASS];
+    std::vector<icl_pending_event> pending;
+    std::vector<hipEvent_t> event_pool;
+    double last_embed_ms = 0, last_dist_ms = 0, last_merge_ms = 0;
+    // subsystems
+    icl_model *model = nullptr;
+    icl_ward_ws *ward = nullptr;
+    std::vector<int32_t> last_merges; // pairs
+};
+
+int icl_fail(icl_ctx *ctx, int code, const char *fmt, ...);
+
+#define ICL_HIP(ctx, call)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return icl_fail(ctx, ICL_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                            __LINE__);                                                                         \
+    } while (0)
+
+#define ICL_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+// RAII: select the context's device for the duration of a call without leaking the change to the caller.
+struct icl_device_guard {
+    int prev = -1;
+    bool ok = true;
+    explicit icl_device_guard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~icl_device_guard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Profiling bracket: when enabled records two events around a launch and attributes algorithmic work.
+struct icl_prof_scope {
+    icl_ctx *c;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    icl_prof_scope(icl_ctx *ctx, int kclass, double flops, double bytes);
+    ~icl_prof_scope();
+};
+void icl_prof_collect(icl_ctx *ctx); // resolves pending events (requires the stream to be idle)
+
+// subsystem teardown hooks
+void icl_model_free(icl_ctx *ctx);
+void icl_ward_free(icl_ctx *ctx);
+
+static inline int64_t icl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// splitmix64: the counter-based hash behind every synthetic input.
+__host__ __device__ static inline uint64_t icl_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// One byte of the synthetic image set: image n, byte offset off in HWC order.
+__host__ __device__ static inline uint8_t icl_synth_pixel(uint64_t seed, int64_t n, uint32_t off, int mode)
+{
+    uint64_t h = icl_splitmix64(seed ^ ((uint64_t)n * (uint64_t)ICL_IMG_BYTES + off));
+    if (mode == ICL_SYNTH_NOISE) return (uint8_t)(h >> 56);
+    // structured: 1000 base patterns made of 16x16-pixel colour blocks, plus +-8 of per-image noise
+    uint32_t c = off % 3u, x = (off / 3u) % ICL_IMG_W, y = off / (3u * ICL_IMG_W);
+    uint64_t cls = (uint64_t)(n % 1000);
+    uint64_t hb = icl_splitmix64((seed * 0x2545F4914F6CDD1Dull) ^ (cls * 4096ull + ((y >> 4) * 14u + (x >> 4)) * 3u + c));
+    int base = (int)(hb >> 56);
+    int noise = (int)((h >> 56) & 15u) - 8;
+    int v = base + noise;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return (uint8_t)v;
+}

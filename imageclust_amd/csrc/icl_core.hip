@@ -1,0 +1,270 @@
+// icl_core.hip -- context, error, memory, profiling and synthetic-input entry points of the C-ABI.
+#include "icl_common.h"
+
+#include <cstring>
+
+static thread_local std::string g_tls_err;
+
+int icl_fail(icl_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_tls_err = buf;
+    return code;
+}
+
+extern "C" const char *icl_version(void) { return "imageclust_hip 0.1 (gfx950)"; }
+
+extern "C" const char *icl_last_error(icl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+extern "C" int icl_create(int device, icl_ctx **out)
+{
+    if (!out) return icl_fail(nullptr, ICL_ERR_ARG, "icl_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return icl_fail(nullptr, ICL_ERR_HIP, "icl_create: no HIP device available (%s); this library has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return icl_fail(nullptr, ICL_ERR_ARG, "icl_create: device %d out of range [0,%d)", device, ndev);
+    icl_ctx *c = new icl_ctx();
+    c->device = device;
+    icl_device_guard g(device);
+    if (!g.ok) {
+        delete c;
+        return icl_fail(nullptr, ICL_ERR_HIP, "icl_create: hipSetDevice(%d) failed", device);
+    }
+    e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return icl_fail(nullptr, ICL_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        delete c;
+        return icl_fail(nullptr, ICL_ERR_HIP, "icl_create: device %d is %s; this library is built for gfx950 only", device, arch.c_str());
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return icl_fail(nullptr, ICL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return ICL_OK;
+}
+
+extern "C" void icl_destroy(icl_ctx *ctx)
+{
+    if (!ctx) return;
+    icl_device_guard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    icl_model_free(ctx);
+    icl_ward_free(ctx);
+    for (auto &p : ctx->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void *icl_stream(icl_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int icl_sync(icl_ctx *ctx)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    icl_prof_collect(ctx);
+    return ICL_OK;
+}
+
+extern "C" int icl_device_info(icl_ctx *ctx, char *name, int cap, int *n_cu, int64_t *hbm)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    if (name && cap > 0) snprintf(name, (size_t)cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)ctx->prop.totalGlobalMem;
+    return ICL_OK;
+}
+
+extern "C" int icl_dev_malloc(icl_ctx *ctx, int64_t bytes, void **dptr)
+{
+    if (!ctx || !dptr || bytes < 0) return icl_fail(ctx, ICL_ERR_ARG, "icl_dev_malloc: bad argument");
+    icl_device_guard g(ctx->device);
+    *dptr = nullptr;
+    if (bytes == 0) return ICL_OK;
+    hipError_t e = hipMalloc(dptr, (size_t)bytes);
+    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return ICL_OK;
+}
+
+extern "C" int icl_dev_free(icl_ctx *ctx, void *dptr)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    icl_device_guard g(ctx->device);
+    if (dptr) {
+        ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ICL_HIP(ctx, hipFree(dptr));
+    }
+    return ICL_OK;
+}
+
+extern "C" int icl_memcpy_h2d(icl_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dst || !src))) return icl_fail(ctx, ICL_ERR_ARG, "icl_memcpy_h2d: bad argument");
+    icl_device_guard g(ctx->device);
+    if (bytes) {
+        ICL_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+        ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ICL_OK;
+}
+
+extern "C" int icl_memcpy_d2h(icl_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dst || !src))) return icl_fail(ctx, ICL_ERR_ARG, "icl_memcpy_d2h: bad argument");
+    icl_device_guard g(ctx->device);
+    if (bytes) {
+        ICL_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ICL_OK;
+}
+
+extern "C" int icl_set_batch(icl_ctx *ctx, int batch)
+{
+    if (!ctx || batch < 1 || batch > 1024) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_batch: batch must be in [1,1024]");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->batch = batch;
+    return ICL_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+static hipEvent_t take_event(icl_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+icl_prof_scope::icl_prof_scope(icl_ctx *ctx, int kclass, double flops, double bytes) : c(ctx), k(kclass)
+{
+    if (!c->prof_on) return;
+    c->prof[k].flops += flops;
+    c->prof[k].bytes += bytes;
+    c->prof[k].launches += 1;
+    a = take_event(c);
+    b = take_event(c);
+    (void)hipEventRecord(a, c->stream);
+}
+
+icl_prof_scope::~icl_prof_scope()
+{
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({a, b, k});
+}
+
+void icl_prof_collect(icl_ctx *ctx)
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->prof[p.kclass].ms += ms;
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int icl_prof_enable(icl_ctx *ctx, int on)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->prof_on = on != 0;
+    return ICL_OK;
+}
+
+extern "C" int icl_prof_reset(icl_ctx *ctx)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    icl_prof_collect(ctx);
+    for (auto &s : ctx->prof) s = icl_prof_slot();
+    return ICL_OK;
+}
+
+extern "C" int icl_prof_query(icl_ctx *ctx, int k, double *ms, int64_t *launches, double *flops, double *bytes)
+{
+    if (!ctx || k < 0 || k >= ICL_K_NCLASS) return ICL_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    icl_prof_collect(ctx);
+    if (ms) *ms = ctx->prof[k].ms;
+    if (launches) *launches = ctx->prof[k].launches;
+    if (flops) *flops = ctx->prof[k].flops;
+    if (bytes) *bytes = ctx->prof[k].bytes;
+    return ICL_OK;
+}
+
+extern "C" int icl_last_stage_ms(icl_ctx *ctx, double *embed_ms, double *dist_ms, double *merge_ms)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    if (embed_ms) *embed_ms = ctx->last_embed_ms;
+    if (dist_ms) *dist_ms = ctx->last_dist_ms;
+    if (merge_ms) *merge_ms = ctx->last_merge_ms;
+    return ICL_OK;
+}
+
+// ---- synthetic images --------------------------------------------------------------------------------------
+extern "C" int icl_synth_images(uint64_t seed, int64_t first, int64_t n, int mode, uint8_t *out)
+{
+    if (n < 0 || first < 0 || (n && !out) || (mode != ICL_SYNTH_NOISE && mode != ICL_SYNTH_STRUCTURED))
+        return icl_fail(nullptr, ICL_ERR_ARG, "icl_synth_images: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t off = 0; off < (uint32_t)ICL_IMG_BYTES; ++off)
+            out[i * ICL_IMG_BYTES + off] = icl_synth_pixel(seed, first + i, off, mode);
+    return ICL_OK;
+}
+
+__global__ void synth_images_kernel(uint64_t seed, int64_t first, int64_t n, int mode, uint8_t *__restrict__ out)
+{
+    // one thread = 4 consecutive bytes of one image (150528 is a multiple of 4)
+    const int64_t total = n * (int64_t)(ICL_IMG_BYTES / 4);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t img = t / (ICL_IMG_BYTES / 4);
+        uint32_t off = (uint32_t)(t % (ICL_IMG_BYTES / 4)) * 4u;
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w |= (uint32_t)icl_synth_pixel(seed, first + img, off + b, mode) << (8 * b);
+        reinterpret_cast<uint32_t *>(out)[t] = w;
+    }
+}
+
+extern "C" int icl_synth_images_dev(icl_ctx *ctx, uint64_t seed, int64_t first, int64_t n, int mode, uint8_t *d_out)
+{
+    if (!ctx || n < 0 || first < 0 || (n && !d_out) || (mode != ICL_SYNTH_NOISE && mode != ICL_SYNTH_STRUCTURED))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_synth_images_dev: bad argument");
+    if (n == 0) return ICL_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    int64_t total = n * (int64_t)(ICL_IMG_BYTES / 4);
+    int blocks = (int)std::min<int64_t>(icl_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(synth_images_kernel, dim3(blocks), dim3(256), 0, ctx->stream, seed, first, n, mode, d_out);
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}

@@ -1,0 +1,943 @@
+// ward.hip -- size-constrained Ward clustering on one MI355X, bit-identical to
+//   /root/reference/internal/clustering/clustering.go
+// (ComputeInitialDistanceMatrix :61-73, FindClosestClusters :119-133, WardDistance :136-157,
+//  MergeClusters :29-47, UpdateDistanceMatrix :76-96, PerformClusteringWithConstraints :198-284).
+//
+// Design (DESIGN.md "Ward engine"): clusters carry a static CREATION ID (singleton i -> i, t-th merge -> N+t).
+// The reference's compacted positions are order-isomorphic to creation ids (RemoveClusters keeps survivor order
+// and the merged cluster is appended last, :55-56,:240-241), so its row-major "first strict minimum" scan
+// (:123-131) is the lexicographic minimum of (value, larger id, smaller id).  The MaxFloat32 ban of oversize
+// pairs (:228-234) is a memo of size_p+size_q > maxSize, and sizes of live clusters never change, so it is a
+// static per-pair mask.  Distances live in a packed lower triangle indexed by creation id; each row keeps a
+// cached (min, argmin) that only needs a rescan when its argmin partner dies.  All arithmetic that feeds a
+// comparison is fp32, unfused, in the reference's order (this file is compiled with -ffp-contract=off).
+#pragma clang fp contract(off)
+
+#include "icl_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct ward_state {
+    int32_t done;      // no mergeable pair left (clustering.go:222-225)
+    int32_t t;         // merges performed so far
+    int32_t rescan_n;  // rows queued for a (min,argmin) rescan
+    int32_t cur_a, cur_b, cur_c; // creation ids: merged pair (a = higher position) and the new cluster
+    int32_t cur_valid; // the current step performed a merge
+    int32_t pad;
+};
+
+struct icl_ward_ws {
+    int64_t capN = 0;
+    int32_t capD = 0;
+    int64_t S = 0, M = 0;
+    float *CT = nullptr;       // [D][S] centroids, transposed: slot-contiguous
+    float *cnew = nullptr;     // [D] centroid of the cluster created by the current step
+    int32_t *slot_id = nullptr;// [S] creation id held by a slot, -1 if free
+    int32_t *id_slot = nullptr;// [M]
+    int32_t *asz = nullptr;    // [M] size if alive else 0
+    float *rowmin = nullptr;   // [M]
+    int32_t *rownn = nullptr;  // [M]
+    int64_t *rowoff = nullptr; // [M+1] float offset of row r in Dtri (rows padded to 4 floats)
+    float *Dtri = nullptr;
+    int64_t dtri_floats = 0;
+    int32_t *merges = nullptr; // [2*N]
+    int32_t *rescan = nullptr; // [M]
+    ward_state *st = nullptr;
+    // find_closest scratch
+    float *fc_min = nullptr;
+    int32_t *fc_nn = nullptr;
+    int64_t fc_cap = 0;
+    int64_t *fc_out = nullptr;
+    std::vector<int64_t> h_rowoff;
+};
+
+void icl_ward_free(icl_ctx *ctx)
+{
+    icl_ward_ws *w = ctx->ward;
+    if (!w) return;
+    void *ptrs[] = {w->CT, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+                    w->merges, w->rescan, w->st, w->fc_min, w->fc_nn, w->fc_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete w;
+    ctx->ward = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6x: exact Ward distance tile.  128x128 pairs per workgroup, 8x8 per lane, sequential k, unfused fp32.
+// ------------------------------------------------------------------------------------------------------------
+#define DT_TILE 128
+#define DT_KC 16
+#define DT_LD (DT_TILE + 4)
+
+__device__ __forceinline__ void tri_decode(int64_t b, int &ti, int &tj)
+{
+    // b = ti*(ti+1)/2 + tj, 0 <= tj <= ti
+    int64_t t = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((t + 1) * (t + 2) / 2 <= b) ++t;
+    while (t * (t + 1) / 2 > b) --t;
+    ti = (int)t;
+    tj = (int)(b - t * (t + 1) / 2);
+}
+
+// mode 0: packed lower triangle (rowoff); mode 1: dense symmetric n x n with leading dimension ld.
+template <int MODE>
+__global__ __launch_bounds__(256) void ward_dist_exact_kernel(const float *__restrict__ X, const int32_t *__restrict__ sizes,
+                                                             int64_t n, int d, float *__restrict__ out,
+                                                             const int64_t *__restrict__ rowoff, int64_t ld)
+{
+    __shared__ __attribute__((aligned(16))) float As[DT_KC][DT_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[DT_KC][DT_LD];
+    int ti, tj;
+    tri_decode(blockIdx.x, ti, tj);
+    const int64_t i0 = (int64_t)ti * DT_TILE, j0 = (int64_t)tj * DT_TILE;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    // staging role: 2 rows per matrix, 4 consecutive k
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const bool vec = (d & 3) == 0;
+
+    float acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0f;
+
+    float ra[2][4], rb[2][4];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ri = i0 + lrow + 64 * h, rj = j0 + lrow + 64 * h;
+            const int k = kc + lk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ra[h][q] = 0.0f; rb[h][q] = 0.0f; }
+            if (ri < n) {
+                if (vec && k + 3 < d) {
+                    float4 v = *reinterpret_cast<const float4 *>(X + ri * d + k);
+                    ra[h][0] = v.x; ra[h][1] = v.y; ra[h][2] = v.z; ra[h][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k + q < d) ra[h][q] = X[ri * d + k + q];
+                }
+            }
+            if (rj < n) {
+                if (vec && k + 3 < d) {
+                    float4 v = *reinterpret_cast<const float4 *>(X + rj * d + k);
+                    rb[h][0] = v.x; rb[h][1] = v.y; rb[h][2] = v.z; rb[h][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k + q < d) rb[h][q] = X[rj * d + k + q];
+                }
+            }
+        }
+    };
+
+    gload(0);
+    for (int kc = 0; kc < d; kc += DT_KC) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                As[lk + q][lrow + 64 * h] = ra[h][q];
+                Bs[lk + q][lrow + 64 * h] = rb[h][q];
+            }
+        __syncthreads();
+        if (kc + DT_KC < d) gload(kc + DT_KC);
+#pragma unroll
+        for (int k = 0; k < DT_KC; ++k) {
+            // zero-padded k beyond d contributes (0-0)^2 = +0: s + 0 == s exactly
+            float4 a0 = *reinterpret_cast<const float4 *>(&As[k][ty * 4]);
+            float4 a1 = *reinterpret_cast<const float4 *>(&As[k][64 + ty * 4]);
+            float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
+            float4 b1 = *reinterpret_cast<const float4 *>(&Bs[k][64 + tx * 4]);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; b += 2) {
+                    f2 av2 = {av[a], av[a]};
+                    f2 bv2 = {bv[b], bv[b + 1]};
+                    f2 s2 = {acc[a][b], acc[a][b + 1]};
+                    f2 df = av2 - bv2;  // clustering.go:139
+                    f2 p = df * df;     // :154 product (rounded)
+                    s2 = s2 + p;        // :154 sum (rounded)
+                    acc[a][b] = s2.x;
+                    acc[a][b + 1] = s2.y;
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: (float(sa*sb)/float(sa+sb)) * sum   (clustering.go:142-144)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int64_t i = i0 + (a < 4 ? ty * 4 + a : 64 + ty * 4 + (a - 4));
+        if (i >= n) continue;
+        const int64_t sa = sizes ? sizes[i] : 1;
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+            const int64_t jb = j0 + bh * 64 + tx * 4;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t j = jb + q;
+                const int64_t sb = (sizes && j < n) ? sizes[j] : 1;
+                const float num = (float)(sa * sb);
+                const float den = (float)(sa + sb);
+                v[q] = (num / den) * acc[a][bh * 4 + q];
+            }
+            if (MODE == 0) {
+                float *row = out + rowoff[i];
+                if (jb + 3 < i) {
+                    *reinterpret_cast<float4 *>(row + jb) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (jb + q < i) row[jb + q] = v[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t j = jb + q;
+                    if (j < i) {
+                        out[i * ld + j] = v[q];
+                        out[j * ld + i] = v[q];
+                    } else if (j == i) {
+                        out[i * ld + i] = 0.0f; // the reference never writes the diagonal (:66)
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K7: masked row argmin.  One workgroup per row: first strict minimum (< MaxFloat32) over the row's live,
+// size-compatible columns, ascending column order (clustering.go:123-131 restricted to one row).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void argmin_combine(float &v, int &i, float ov, int oi)
+{
+    // lexicographic (value, index): "first minimum in scan order"
+    if (ov < v || (ov == v && oi >= 0 && (i < 0 || oi < i))) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__device__ __forceinline__ void block_argmin(float &v, int &i, float *sv, int *si)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ov = __shfl_down(v, off, 64);
+        int oi = __shfl_down(i, off, 64);
+        argmin_combine(v, i, ov, oi);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sv[wid] = v;
+        si[wid] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = sv[0];
+        int bi = si[0];
+        for (int w = 1; w < nw; ++w) argmin_combine(bv, bi, sv[w], si[w]);
+        sv[0] = bv;
+        si[0] = bi;
+    }
+    __syncthreads();
+    v = sv[0];
+    i = si[0];
+    __syncthreads();
+}
+
+// Scans row r (len = number of candidate columns 0..len-1).  asz == nullptr: no mask (dense API matrix).
+__device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz,
+                                         int my_size, int max_size, float &bv, int &bi)
+{
+    bv = ICL_MAXF;
+    bi = -1;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    const int64_t nvec = aligned ? (len >> 2) : 0;
+    for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(row)[q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        int4 m = make_int4(1, 1, 1, 1);
+        if (asz) m = reinterpret_cast<const int4 *>(asz)[q];
+        const int mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = asz ? (mm[e] > 0 && mm[e] + my_size <= max_size) : true;
+            if (ok && vv[e] < bv) {
+                bv = vv[e];
+                bi = (int)(q * 4 + e);
+            }
+        }
+    }
+    // tail (and the whole row when it is not 16-byte aligned); a thread's tail indices exceed all its earlier ones
+    for (int64_t c = nvec * 4 + threadIdx.x; c < len; c += blockDim.x) {
+        const float v = row[c];
+        const int m = asz ? asz[c] : 1;
+        const bool ok = asz ? (m > 0 && m + my_size <= max_size) : true;
+        if (ok && v < bv) {
+            bv = v;
+            bi = (int)c;
+        }
+    }
+}
+
+// rows: explicit list (list != nullptr, *count entries) or 0..nrows-1.  Packed triangle addressing.
+__global__ __launch_bounds__(256) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
+                                                            const int32_t *__restrict__ asz, int max_size,
+                                                            const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                                            int64_t nrows, const ward_state *__restrict__ st,
+                                                            float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+{
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if (st && st->done) return;
+    const int64_t total = list ? (int64_t)(*count) : nrows;
+    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const int64_t r = list ? list[idx] : idx;
+        const int my = asz[r];
+        float bv;
+        int bi;
+        if (my <= 0) {
+            bv = ICL_MAXF;
+            bi = -1;
+        } else {
+            scan_row(Dtri + rowoff[r], r, asz, my, max_size, bv, bi);
+        }
+        block_argmin(bv, bi, sv, si);
+        if (threadIdx.x == 0) {
+            rowmin[r] = bv;
+            rownn[r] = bi;
+        }
+    }
+}
+
+// Dense n x n matrix (API FindClosestClusters): row r scans columns 0..r-1, no mask.
+__global__ __launch_bounds__(256) void row_argmin_dense_kernel(const float *__restrict__ D, int64_t n, int64_t ld,
+                                                              float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+{
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        float bv;
+        int bi;
+        scan_row(D + r * ld, r, nullptr, 0, 0, bv, bi);
+        block_argmin(bv, bi, sv, si);
+        if (threadIdx.x == 0) {
+            rowmin[r] = bv;
+            rownn[r] = bi;
+        }
+    }
+}
+
+// Final reduce for the dense API: lexicographic (value,row) minimum -> (i,j) or (-1,-1).
+__global__ __launch_bounds__(1024) void select_dense_kernel(const float *__restrict__ rowmin, const int32_t *__restrict__ rownn,
+                                                           int64_t n, int64_t *__restrict__ out)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    float bv = ICL_MAXF;
+    int bi = -1;
+    for (int64_t r = threadIdx.x; r < n; r += blockDim.x) {
+        const float v = rowmin[r];
+        if (v < bv) {
+            bv = v;
+            bi = (int)r;
+        }
+    }
+    block_argmin(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        out[0] = bi;
+        out[1] = bi >= 0 ? rownn[bi] : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Merge loop kernels
+// ------------------------------------------------------------------------------------------------------------
+__global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_id, int32_t *id_slot, int32_t *asz,
+                                 float *rowmin, int32_t *rownn, ward_state *st)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) slot_id[i] = i < n ? (int32_t)i : -1;
+    if (i < M) {
+        id_slot[i] = i < n ? (int32_t)i : -1;
+        asz[i] = i < n ? 1 : 0;
+        rowmin[i] = ICL_MAXF;
+        rownn[i] = -1;
+    }
+    if (i == 0) {
+        st->done = 0;
+        st->t = 0;
+        st->rescan_n = 0;
+        st->cur_a = st->cur_b = st->cur_c = -1;
+        st->cur_valid = 0;
+    }
+}
+
+// E [n][d] row-major -> CT [d][S] (slot-contiguous), 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ E, int64_t n, int d, int64_t S,
+                                                       float *__restrict__ CT)
+{
+    __shared__ float tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 8 rows per pass
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int64_t r = r0 + rr;
+        const int k = k0 + tx;
+        tile[rr][tx] = (r < n && k < d) ? E[r * d + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int k = k0 + kk;
+        const int64_t r = r0 + tx;
+        if (k < d && r < S) CT[(int64_t)k * S + r] = tile[tx][kk];
+    }
+}
+
+// Step 1/3: pick the globally closest admissible pair and create the merged cluster.
+__global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT,
+                                                          float *__restrict__ cnew, int32_t *__restrict__ slot_id,
+                                                          int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
+                                                          float *__restrict__ rowmin, const int32_t *__restrict__ rownn,
+                                                          int32_t *__restrict__ merges, int32_t *__restrict__ rescan,
+                                                          ward_state *__restrict__ st)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int sh[4];
+    if (st->done) return;
+    const int t = st->t;
+    const int64_t nrows = n + t;
+    float bv = ICL_MAXF;
+    int bi = -1;
+    for (int64_t r = threadIdx.x; r < nrows; r += blockDim.x) {
+        const float v = rowmin[r];
+        if (v < bv) { // strict: first row wins among equal minima (clustering.go:125)
+            bv = v;
+            bi = (int)r;
+        }
+    }
+    block_argmin(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        if (bi < 0) {
+            st->done = 1; // clustering.go:222-225 "No more clusters to merge."
+            st->cur_valid = 0;
+            st->rescan_n = 0;
+            sh[0] = -1;
+        } else {
+            const int a = bi, b = rownn[bi], c = (int)(n + t);
+            sh[0] = a;
+            sh[1] = b;
+            sh[2] = asz[a];
+            sh[3] = asz[b];
+        }
+    }
+    __syncthreads();
+    const int a = sh[0];
+    if (a < 0) return;
+    const int b = sh[1], sa = sh[2], sb = sh[3];
+    const int c = (int)(n + t);
+    const int slot_a = id_slot[a], slot_b = id_slot[b];
+    // MergeClusters centroid (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb) / float(sa+sb), each op rounded
+    const float fa = (float)sa, fb = (float)sb, fs = (float)(sa + sb);
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float pa = fa * CT[(int64_t)k * S + slot_a];
+        const float pb = fb * CT[(int64_t)k * S + slot_b];
+        const float s = pa + pb;
+        const float cv = s / fs;
+        cnew[k] = cv;
+        CT[(int64_t)k * S + slot_a] = cv; // the new cluster inherits a's slot
+    }
+    if (threadIdx.x == 0) {
+        merges[2 * t] = a;
+        merges[2 * t + 1] = b;
+        asz[a] = 0;
+        asz[b] = 0;
+        asz[c] = sa + sb;
+        rowmin[a] = ICL_MAXF;
+        rowmin[b] = ICL_MAXF;
+        rowmin[c] = ICL_MAXF;
+        id_slot[c] = slot_a;
+        slot_id[slot_a] = c;
+        slot_id[slot_b] = -1;
+        rescan[0] = c;
+        st->rescan_n = 1;
+        st->cur_a = a;
+        st->cur_b = b;
+        st->cur_c = c;
+        st->cur_valid = 1;
+        st->t = t + 1;
+    }
+}
+
+// Step 2/3 (K8 exact): one lane per slot: WardDistance(x, new) from centroids (clustering.go:84), sequential k,
+// written into the new cluster's row; rows whose cached argmin just died are queued for a rescan.
+#define UPD_U 16
+__global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int64_t S, const float *__restrict__ CT,
+                                                               const float *__restrict__ cnew,
+                                                               const int32_t *__restrict__ slot_id,
+                                                               const int32_t *__restrict__ asz, const int32_t *__restrict__ rownn,
+                                                               const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                               int32_t *__restrict__ rescan, ward_state *__restrict__ st,
+                                                               int max_size)
+{
+    if (st->done || !st->cur_valid) return;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= S) return;
+    const int x = slot_id[slot];
+    const int a = st->cur_a, b = st->cur_b, c = st->cur_c;
+    if (x < 0 || x == c) return;
+    const int sx = asz[x];
+    if (sx <= 0) return;
+    const int nn = rownn[x];
+    if (nn == a || nn == b) {
+        const int pos = atomicAdd(&st->rescan_n, 1);
+        rescan[pos] = x;
+    }
+    const int sc = asz[c];
+    if (sx + sc > max_size) return; // pair is banned for good (static mask); its value is never read
+    const float *col = CT + slot;
+    float s = 0.0f;
+    int k = 0;
+    for (; k + UPD_U <= d; k += UPD_U) {
+        float v[UPD_U];
+#pragma unroll
+        for (int u = 0; u < UPD_U; ++u) v[u] = col[(int64_t)(k + u) * S];
+#pragma unroll
+        for (int u = 0; u < UPD_U; ++u) {
+            const float df = v[u] - cnew[k + u]; // clusters[i].Centroid - newCluster.Centroid (:139 via :84)
+            const float p = df * df;
+            s = s + p;
+        }
+    }
+    for (; k < d; ++k) {
+        const float df = col[(int64_t)k * S] - cnew[k];
+        const float p = df * df;
+        s = s + p;
+    }
+    const float num = (float)((int64_t)sx * (int64_t)sc);
+    const float den = (float)(sx + sc);
+    Dtri[rowoff[c] + x] = (num / den) * s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
+{
+    if (!ctx->ward) ctx->ward = new icl_ward_ws();
+    icl_ward_ws *w = ctx->ward;
+    if (w->capN >= n && w->capD >= d && w->capN > 0) {
+        // keep geometry consistent with the current problem (S, M depend on n)
+    }
+    if (w->capN != n || w->capD != d) {
+        // (re)allocate for exactly this shape
+        void *ptrs[] = {w->CT, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+                        w->merges, w->rescan, w->st};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        w->CT = w->cnew = w->rowmin = w->Dtri = nullptr;
+        w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = w->rescan = nullptr;
+        w->rowoff = nullptr;
+        w->st = nullptr;
+        w->capN = 0;
+        w->S = (n + 63) / 64 * 64;
+        if (w->S == 0) w->S = 64;
+        w->M = 2 * n + 4; // padded so int4 mask loads on any row prefix stay in bounds
+        w->M = (w->M + 3) / 4 * 4;
+        w->h_rowoff.resize((size_t)w->M + 1);
+        int64_t off = 0;
+        for (int64_t r = 0; r <= w->M; ++r) {
+            w->h_rowoff[(size_t)r] = off;
+            off += (r + 3) / 4 * 4;
+        }
+        w->dtri_floats = off;
+        const int64_t dd = d > 0 ? d : 1;
+#define WS_ALLOC(field, type, count)                                                                             \
+    do {                                                                                                         \
+        hipError_t e__ = hipMalloc((void **)&w->field, (size_t)std::max<int64_t>((int64_t)(count), 1) * sizeof(type)); \
+        if (e__ != hipSuccess)                                                                                   \
+            return icl_fail(ctx, ICL_ERR_NOMEM, "ward workspace: hipMalloc(%s, %lld x %zu B) failed: %s", #field, \
+                            (long long)(count), sizeof(type), hipGetErrorString(e__));                          \
+    } while (0)
+        WS_ALLOC(CT, float, dd * w->S);
+        WS_ALLOC(cnew, float, dd);
+        WS_ALLOC(slot_id, int32_t, w->S);
+        WS_ALLOC(id_slot, int32_t, w->M);
+        WS_ALLOC(asz, int32_t, w->M);
+        WS_ALLOC(rowmin, float, w->M);
+        WS_ALLOC(rownn, int32_t, w->M);
+        WS_ALLOC(rowoff, int64_t, w->M + 1);
+        WS_ALLOC(Dtri, float, w->dtri_floats);
+        WS_ALLOC(merges, int32_t, 2 * n + 2);
+        WS_ALLOC(rescan, int32_t, w->M);
+        WS_ALLOC(st, ward_state, 1);
+        ICL_HIP(ctx, hipMemcpyAsync(w->rowoff, w->h_rowoff.data(), (size_t)(w->M + 1) * sizeof(int64_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        w->capN = n;
+        w->capD = d;
+    }
+    return ICL_OK;
+}
+
+static int fc_ensure(icl_ctx *ctx, int64_t n)
+{
+    if (!ctx->ward) ctx->ward = new icl_ward_ws();
+    icl_ward_ws *w = ctx->ward;
+    if (w->fc_cap < n || !w->fc_out) {
+        if (w->fc_min) (void)hipFree(w->fc_min);
+        if (w->fc_nn) (void)hipFree(w->fc_nn);
+        w->fc_min = nullptr;
+        w->fc_nn = nullptr;
+        ICL_HIP(ctx, hipMalloc((void **)&w->fc_min, (size_t)std::max<int64_t>(n, 1) * sizeof(float)));
+        ICL_HIP(ctx, hipMalloc((void **)&w->fc_nn, (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
+        if (!w->fc_out) ICL_HIP(ctx, hipMalloc((void **)&w->fc_out, 2 * sizeof(int64_t)));
+        w->fc_cap = n;
+    }
+    return ICL_OK;
+}
+
+extern "C" int icl_calc_optimal_clusters(int64_t total, int64_t min_size, int64_t max_size, int64_t *k)
+{
+    // clustering.go:168-186.  min/max < 1 divide by zero in the reference (implementation-defined int
+    // conversion of +Inf); rejected here.
+    if (!k) return ICL_ERR_ARG;
+    if (min_size < 1 || max_size < 1) return ICL_ERR_CONSTRAINT;
+    if (total < min_size) return ICL_ERR_CONSTRAINT;
+    const int64_t lo = (int64_t)std::ceil((double)total / (double)max_size);
+    const int64_t hi = (int64_t)std::floor((double)total / (double)min_size);
+    if (lo > hi) return ICL_ERR_CONSTRAINT;
+    *k = lo < hi ? (lo + hi) / 2 : lo;
+    return ICL_OK;
+}
+
+static int launch_dist_exact(icl_ctx *ctx, const float *d_X, const int32_t *d_sizes, int64_t n, int d, float *out,
+                             const int64_t *rowoff, int64_t ld, int mode)
+{
+    if (n <= 0) return ICL_OK;
+    const int64_t nt = icl_ceil_div(n, DT_TILE);
+    const int64_t nblocks = nt * (nt + 1) / 2;
+    if (nblocks > 0x7fffffffLL) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "distance tile grid too large (n=%lld)", (long long)n);
+    const double pairs = (double)n * (double)(n - 1) * 0.5;
+    icl_prof_scope ps(ctx, ICL_K_DIST_EXACT, pairs * 3.0 * d, 4.0 * n * d + 4.0 * pairs);
+    if (mode == 0)
+        hipLaunchKernelGGL(ward_dist_exact_kernel<0>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
+                           out, rowoff, ld);
+    else
+        hipLaunchKernelGGL(ward_dist_exact_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
+                           out, rowoff, ld);
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}
+
+extern "C" int icl_ward_distance_matrix_dev(icl_ctx *ctx, const float *d_C, const int32_t *d_sizes, int64_t n, int32_t d,
+                                            float *d_D, int64_t ld)
+{
+    if (!ctx || n < 0 || d < 0 || ld < n || (n && (!d_C || !d_D)))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_distance_matrix_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_TRY(launch_dist_exact(ctx, d_C, d_sizes, n, d, d_D, nullptr, ld, 1));
+    return ICL_OK;
+}
+
+extern "C" int icl_ward_distance_matrix(icl_ctx *ctx, const float *C, const int32_t *sizes, int64_t n, int32_t d, float *D,
+                                        int64_t ld)
+{
+    if (!ctx || n < 0 || d < 0 || ld < n || (n && (!C || !D))) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_distance_matrix: bad argument");
+    if (n == 0) return ICL_OK;
+    float *dC = nullptr, *dD = nullptr;
+    int32_t *dS = nullptr;
+    int rc = ICL_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        icl_device_guard g(ctx->device);
+        ICL_HIP(ctx, hipMalloc((void **)&dC, (size_t)std::max<int64_t>(n * d, 1) * 4));
+        ICL_HIP(ctx, hipMalloc((void **)&dD, (size_t)(n * n) * 4));
+        if (sizes) ICL_HIP(ctx, hipMalloc((void **)&dS, (size_t)n * 4));
+        ICL_HIP(ctx, hipMemcpyAsync(dC, C, (size_t)(n * d) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (sizes) ICL_HIP(ctx, hipMemcpyAsync(dS, sizes, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        rc = launch_dist_exact(ctx, dC, dS, n, d, dD, nullptr, n, 1);
+        if (rc == ICL_OK) {
+            hipError_t e = hipMemcpy2DAsync(D, (size_t)ld * 4, dD, (size_t)n * 4, (size_t)n * 4, (size_t)n, hipMemcpyDeviceToHost,
+                                            ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "distance matrix copy-back failed: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(dC);
+        (void)hipFree(dD);
+        if (dS) (void)hipFree(dS);
+    }
+    return rc;
+}
+
+static int find_closest_locked(icl_ctx *ctx, const float *d_D, int64_t n, int64_t ld, int64_t *i, int64_t *j)
+{
+    *i = -1;
+    *j = -1;
+    if (n < 2) return ICL_OK;
+    ICL_TRY(fc_ensure(ctx, n));
+    icl_ward_ws *w = ctx->ward;
+    {
+        icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
+        const int blocks = (int)std::min<int64_t>(n, 256 * 32);
+        hipLaunchKernelGGL(row_argmin_dense_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_D, n, ld, w->fc_min, w->fc_nn);
+    }
+    hipLaunchKernelGGL(select_dense_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->fc_min, w->fc_nn, n, w->fc_out);
+    ICL_HIP(ctx, hipGetLastError());
+    int64_t h[2];
+    ICL_HIP(ctx, hipMemcpyAsync(h, w->fc_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *i = h[0];
+    *j = h[1];
+    return ICL_OK;
+}
+
+extern "C" int icl_find_closest_dev(icl_ctx *ctx, const float *d_D, int64_t n, int64_t ld, int64_t *i, int64_t *j)
+{
+    if (!ctx || n < 0 || ld < n || !i || !j || (n && !d_D)) return icl_fail(ctx, ICL_ERR_ARG, "icl_find_closest_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    return find_closest_locked(ctx, d_D, n, ld, i, j);
+}
+
+extern "C" int icl_find_closest(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, int64_t *i, int64_t *j)
+{
+    if (!ctx || n < 0 || ld < n || !i || !j || (n && !D)) return icl_fail(ctx, ICL_ERR_ARG, "icl_find_closest: bad argument");
+    *i = -1;
+    *j = -1;
+    if (n < 2) return ICL_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    float *dD = nullptr;
+    ICL_HIP(ctx, hipMalloc((void **)&dD, (size_t)(n * ld) * 4));
+    hipError_t e = hipMemcpyAsync(dD, D, (size_t)(n * ld) * 4, hipMemcpyHostToDevice, ctx->stream);
+    int rc = e == hipSuccess ? find_closest_locked(ctx, dD, n, ld, i, j)
+                             : icl_fail(ctx, ICL_ERR_HIP, "find_closest upload failed: %s", hipGetErrorString(e));
+    (void)hipFree(dD);
+    return rc;
+}
+
+// Build the reference's final cluster list from the merge log (clustering.go:265-280 and SURVEY.md 8a C11):
+// surviving singletons in index order, then merged clusters in creation order; members of Merge(a,b) are
+// a's then b's (:31); clusters below min_size are dropped and consume no id.
+static int assign_ids(icl_ctx *ctx, int64_t n, int32_t min_size, int32_t max_size, const std::vector<int32_t> &pairs,
+                      int64_t nmerge, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    const int64_t M = n + nmerge;
+    std::vector<int32_t> left((size_t)M, -1), right((size_t)M, -1), size((size_t)M, 1);
+    std::vector<uint8_t> alive((size_t)M, 1);
+    for (int64_t t = 0; t < nmerge; ++t) {
+        const int32_t a = pairs[2 * t], b = pairs[2 * t + 1];
+        const int64_t c = n + t;
+        if (a < 0 || b < 0 || a >= c || b >= c || !alive[a] || !alive[b])
+            return icl_fail(ctx, ICL_ERR_HIP, "corrupt merge log at step %lld (%d,%d)", (long long)t, a, b);
+        left[c] = a;
+        right[c] = b;
+        size[c] = size[a] + size[b];
+        alive[a] = alive[b] = 0;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        cluster_id[i] = -1;
+        member_rank[i] = -1;
+    }
+    int32_t cid = 0;
+    int rc = ICL_OK;
+    std::vector<int32_t> stack;
+    for (int64_t c = 0; c < M; ++c) {
+        if (!alive[c]) continue;
+        if (size[c] > max_size) rc = icl_fail(ctx, ICL_ERR_OVERSIZE, "cluster of size %d exceeds maxSize %d (splitCluster is not implemented)", size[c], max_size);
+        if (size[c] < min_size) continue; // clustering.go:268-271
+        int32_t rank = 0;
+        stack.clear();
+        stack.push_back((int32_t)c);
+        while (!stack.empty()) {
+            const int32_t x = stack.back();
+            stack.pop_back();
+            if (x < n) {
+                cluster_id[x] = cid;
+                member_rank[x] = rank++;
+            } else {
+                stack.push_back(right[x]); // visited after left: a's members first
+                stack.push_back(left[x]);
+            }
+        }
+        ++cid;
+    }
+    *n_clusters = cid;
+    return rc;
+}
+
+static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                          int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    int64_t k = 0;
+    if (icl_calc_optimal_clusters(n, min_size, max_size, &k) != ICL_OK)
+        return icl_fail(ctx, ICL_ERR_CONSTRAINT, "cannot satisfy cluster size constraints with total items (%lld), minSize (%d), and maxSize (%d)",
+                        (long long)n, min_size, max_size);
+    if (update != ICL_UPDATE_EXACT) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "update mode %d is not available in this build", update);
+    if (n >= (1LL << 30)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "n too large");
+    ctx->last_merges.clear();
+    *n_clusters = 0;
+    const int64_t T = n - k; // merges needed for len(clusters) == k (clustering.go:220)
+    if (n == 0) return ICL_OK;
+    ICL_TRY(ward_ensure(ctx, n, d));
+    icl_ward_ws *w = ctx->ward;
+    hipEvent_t e0, e1, e2;
+    ICL_HIP(ctx, hipEventCreate(&e0));
+    ICL_HIP(ctx, hipEventCreate(&e1));
+    ICL_HIP(ctx, hipEventCreate(&e2));
+    ICL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+
+    {
+        const int64_t cnt = std::max(w->S, w->M);
+        hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, ctx->stream, n, w->S, w->M,
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->st);
+        if (d > 0)
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)icl_ceil_div(w->S, 32), (unsigned)icl_ceil_div(d, 32)), dim3(256), 0,
+                               ctx->stream, d_E, n, d, w->S, w->CT);
+        ICL_HIP(ctx, hipGetLastError());
+    }
+    // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle
+    ICL_TRY(launch_dist_exact(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0));
+    {
+        icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
+        const int blocks = (int)std::min<int64_t>(n, 256 * 64);
+        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, n, (const ward_state *)nullptr, w->rowmin, w->rownn);
+        ICL_HIP(ctx, hipGetLastError());
+    }
+    ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+
+    const unsigned upd_blocks = (unsigned)icl_ceil_div(w->S, 256);
+    for (int64_t t = 0; t < T; ++t) {
+        hipLaunchKernelGGL(ward_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->cnew, w->slot_id,
+                           w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->rescan, w->st);
+        {
+            icl_prof_scope ps(ctx, ICL_K_UPDATE, 3.0 * (double)(n - t) * d, 4.0 * (double)(n - t) * d);
+            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), 0, ctx->stream, d, w->S, w->CT, w->cnew,
+                               w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
+        }
+        {
+            icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 0.0);
+            hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(64), dim3(256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
+                               w->rescan, &w->st->rescan_n, (int64_t)0, w->st, w->rowmin, w->rownn);
+        }
+    }
+    ICL_HIP(ctx, hipGetLastError());
+    ICL_HIP(ctx, hipEventRecord(e2, ctx->stream));
+
+    ward_state hst;
+    ICL_HIP(ctx, hipMemcpyAsync(&hst, w->st, sizeof hst, hipMemcpyDeviceToHost, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t nmerge = hst.t;
+    std::vector<int32_t> pairs((size_t)(2 * nmerge));
+    if (nmerge) {
+        ICL_HIP(ctx, hipMemcpyAsync(pairs.data(), w->merges, (size_t)(2 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    float ms01 = 0, ms12 = 0;
+    (void)hipEventElapsedTime(&ms01, e0, e1);
+    (void)hipEventElapsedTime(&ms12, e1, e2);
+    ctx->last_dist_ms = ms01;
+    ctx->last_merge_ms = ms12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    icl_prof_collect(ctx);
+    int rc = assign_ids(ctx, n, min_size, max_size, pairs, nmerge, cluster_id, member_rank, n_clusters);
+    ctx->last_merges.swap(pairs);
+    return rc;
+}
+
+extern "C" int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,
+                               int update, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!d_E || !cluster_id || !member_rank)))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+}
+
+extern "C" int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                           int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!E || !cluster_id || !member_rank)))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    float *dE = nullptr;
+    if (n * d > 0) {
+        ICL_HIP(ctx, hipMalloc((void **)&dE, (size_t)(n * d) * 4));
+        hipError_t e = hipMemcpyAsync(dE, E, (size_t)(n * d) * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(dE);
+            return icl_fail(ctx, ICL_ERR_HIP, "icl_cluster upload failed: %s", hipGetErrorString(e));
+        }
+    } else if (n > 0) {
+        ICL_HIP(ctx, hipMalloc((void **)&dE, 16));
+    }
+    int rc = cluster_locked(ctx, dE, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+    if (dE) (void)hipFree(dE);
+    return rc;
+}
+
+__global__ void merge_centroid_kernel(const float *__restrict__ ca, float fa, const float *__restrict__ cb, float fb, float fs,
+                                      int d, float *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d) return;
+    const float pa = fa * ca[k];
+    const float pb = fb * cb[k];
+    const float s = pa + pb;
+    out[k] = s / fs;
+}
+
+extern "C" int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, const float *cb, int64_t sb, int32_t d, float *out)
+{
+    if (!ctx || d < 0 || (d && (!ca || !cb || !out))) return icl_fail(ctx, ICL_ERR_ARG, "icl_merge_centroid: bad argument");
+    if (d == 0) return ICL_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    float *buf = nullptr;
+    ICL_HIP(ctx, hipMalloc((void **)&buf, (size_t)d * 12));
+    hipError_t e = hipMemcpyAsync(buf, ca, (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf + d, cb, (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(merge_centroid_kernel, dim3((unsigned)icl_ceil_div(d, 256)), dim3(256), 0, ctx->stream, buf, (float)sa,
+                           buf + d, (float)sb, (float)(sa + sb), d, buf + 2 * (int64_t)d);
+        e = hipMemcpyAsync(out, buf + 2 * (int64_t)d, (size_t)d * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "icl_merge_centroid: %s", hipGetErrorString(e));
+    return ICL_OK;
+}
+
+extern "C" int64_t icl_last_merges(icl_ctx *ctx, int32_t *pairs, int64_t cap_pairs)
+{
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int64_t nm = (int64_t)ctx->last_merges.size() / 2;
+    if (pairs)
+        for (int64_t t = 0; t < std::min(nm, cap_pairs); ++t) {
+            pairs[2 * t] = ctx->last_merges[(size_t)(2 * t)];
+            pairs[2 * t + 1] = ctx->last_merges[(size_t)(2 * t + 1)];
+        }
+    return nm;
+}

@@ -1,0 +1,142 @@
+/*
+ * imageclust.h -- C-ABI of libimageclust_hip.so, the MI355X (gfx950) engine that stands in for the
+ * embed + Ward-cluster hot path of monahand1023/imageclust.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, int status codes, caller-owned outputs, no C++
+ * exceptions, no torch types.  Each entry point names the reference interface it replaces (file:line under
+ * /root/reference).  The Go binding a maintainer adds is shown in INTEGRATION.md and go/.
+ *
+ * Conventions
+ *   - every function returns ICL_OK (0) or an ICL_ERR_* code; icl_last_error() gives the text.
+ *   - matrices are row-major; "host" pointers are ordinary memory, "_dev" variants take device pointers that
+ *     live on the context's GPU and are consumed on the context's stream (icl_stream()).
+ *   - all entry points are thread-safe (a context serialises its own calls with a mutex): the reference calls
+ *     GetImageEmbedding from N goroutines (internal/workflow/workflow.go:156-175).
+ *   - one context drives ONE GPU; multi-GPU jobs run one process (or one context) per GPU and exchange E with
+ *     RCCL outside this ABI (bench.py, imageclust_amd/distributed.py).
+ */
+#ifndef IMAGECLUST_H
+#define IMAGECLUST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icl_ctx icl_ctx;
+
+enum {
+    ICL_OK = 0,
+    ICL_ERR_ARG = 1,         /* bad argument (null, negative size, unknown enum) */
+    ICL_ERR_CONSTRAINT = 2,  /* clustering.go:204-207,175-177: constraints cannot be met -> (nil,false) */
+    ICL_ERR_HIP = 3,         /* a HIP runtime call failed / no usable gfx950 device */
+    ICL_ERR_NOMODEL = 4,     /* embed called before a model was loaded */
+    ICL_ERR_IO = 5,          /* file missing / unreadable / malformed */
+    ICL_ERR_UNSUPPORTED = 6, /* valid request this build cannot serve */
+    ICL_ERR_OVERSIZE = 7,    /* a cluster above maxSize was observed (clustering.go:251; unreachable) */
+    ICL_ERR_NOMEM = 8
+};
+
+enum { ICL_HEAD_POOLED = 2048, /* global-average-pool vector (north_star) */
+       ICL_HEAD_DENSE0 = 1000  /* "resnetv17_dense0_fwd" (embeddings.go:140) */ };
+enum { ICL_PREC_FP32 = 0, /* f32 MFMA, parity mode (<=1e-4 vs the fp32 restatement) */
+       ICL_PREC_BF16 = 1  /* bf16 MFMA with fp32 accumulate, throughput mode */ };
+enum { ICL_UPDATE_EXACT = 0, /* centroid recompute, bit-identical to clustering.go:76-96 */
+       ICL_UPDATE_LW = 1     /* MFMA distance tile + Lance-Williams rows: fast, NOT bit-identical */ };
+enum { ICL_SYNTH_NOISE = 0, ICL_SYNTH_STRUCTURED = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int icl_create(int device_ordinal, icl_ctx **out);
+void icl_destroy(icl_ctx *ctx);
+/* Last error text of ctx (or of the calling thread's last failed icl_create when ctx == NULL). */
+const char *icl_last_error(icl_ctx *ctx);
+/* hipStream_t (as void*) every kernel of this context is launched on. */
+void *icl_stream(icl_ctx *ctx);
+int icl_sync(icl_ctx *ctx);
+int icl_device_info(icl_ctx *ctx, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes);
+/* Device memory helpers for hosts that have no allocator of their own (Go shim, ctypes tests). */
+int icl_dev_malloc(icl_ctx *ctx, int64_t bytes, void **dptr);
+int icl_dev_free(icl_ctx *ctx, void *dptr);
+int icl_memcpy_h2d(icl_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
+int icl_memcpy_d2h(icl_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
+
+/* ---- model: replaces LoadPretrainedModelONNX (internal/embeddings/embeddings.go:28-43) ------------------- */
+/* Parse an ONNX file's initializers (no protobuf dependency) into the context. */
+int icl_model_load_onnx(icl_ctx *ctx, const char *path);
+/* Load an "ICLW" blob (include/icl_model_format.h). */
+int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes);
+/* Seeded synthetic ResNet50-v1 weights: generate on the host, then load. */
+int icl_model_load_synthetic(icl_ctx *ctx, uint64_t seed);
+int64_t icl_synthetic_blob_bytes(void);
+int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes); /* host only, no GPU needed */
+
+/* ---- embed: replaces PreprocessImage + GetImageEmbedding (embeddings.go:46-116,119-163) ----------------- */
+/* n images, each 224*224*3 u8, HWC, RGB (i.e. after the reference's resize + BGR->RGB).  out is n x head fp32.
+ * head: ICL_HEAD_POOLED or ICL_HEAD_DENSE0.  prec: ICL_PREC_*.  Batches internally (default 256). */
+int icl_embed_u8(icl_ctx *ctx, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
+int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head, int prec, float *d_out);
+/* One image file (binary PPM "P6" today; JPEG is SURVEY.md 8f-2): decode, bilinear resize to 224x224
+ * (embeddings.go:69), then as icl_embed_u8 with n = 1, fp32. */
+int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
+/* PreprocessImage alone: the 1x3x224x224 fp32 NCHW blob of embeddings.go:96-108 (host). */
+int icl_preprocess_u8(const uint8_t *hwc_rgb, float *nchw);
+int icl_set_batch(icl_ctx *ctx, int batch); /* embed batch size, 1..1024 */
+
+/* ---- Ward clustering: replaces internal/clustering/clustering.go --------------------------------------- */
+/* CalculateOptimalClusters (clustering.go:168-186). ICL_ERR_CONSTRAINT on the reference's error branches. */
+int icl_calc_optimal_clusters(int64_t total, int64_t min_size, int64_t max_size, int64_t *k);
+/* ComputeInitialDistanceMatrix (clustering.go:61-73) for n clusters with centroids C (n x d) and sizes
+ * (NULL = all 1).  D is n x n with leading dimension ld, symmetric, diagonal 0.  Bit-identical. */
+int icl_ward_distance_matrix(icl_ctx *ctx, const float *C, const int32_t *sizes, int64_t n, int32_t d, float *D,
+                             int64_t ld);
+int icl_ward_distance_matrix_dev(icl_ctx *ctx, const float *d_C, const int32_t *d_sizes, int64_t n, int32_t d,
+                                 float *d_D, int64_t ld);
+/* Centroid of MergeClusters(a,b) (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb)/float(sa+sb), host pointers. */
+int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, const float *cb, int64_t sb, int32_t d, float *out);
+/* FindClosestClusters (clustering.go:119-133): first strict minimum of the lower triangle in row-major
+ * order; (-1,-1) if none is < MaxFloat32. */
+int icl_find_closest(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, int64_t *i, int64_t *j);
+int icl_find_closest_dev(icl_ctx *ctx, const float *d_D, int64_t n, int64_t ld, int64_t *i, int64_t *j);
+/* PerformClusteringWithConstraints (clustering.go:198-284) on E (n x d).  Canonical output:
+ * cluster_id[i] = dense id of the kept cluster of image i, or -1 if its cluster was dropped (< min_size);
+ * member_rank[i] = position of image i in that cluster's member list.  Returns ICL_ERR_CONSTRAINT for the
+ * reference's (nil,false). */
+int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,
+                    int update, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+/* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
+ * cluster, creation id of the lower-position one); returns the number of merges performed. */
+int64_t icl_last_merges(icl_ctx *ctx, int32_t *pairs, int64_t cap_pairs);
+/* MFMA distance tile alone (north_star K6): D~[i][j] = 0.5*(|e_i|^2+|e_j|^2-2 e_i.e_j), bf16x3 split operands,
+ * fp32 accumulate; lower triangle incl. diagonal written, packed row-major with leading dimension ld. */
+int icl_distance_mfma_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, float *d_D, int64_t ld);
+
+/* ---- synthetic inputs ---------------------------------------------------------------------- */
+/* Images first..first+n-1 of the seeded synthetic set, u8 HWC RGB 224x224x3. */
+int icl_synth_images(uint64_t seed, int64_t first, int64_t n, int mode, uint8_t *out);
+int icl_synth_images_dev(icl_ctx *ctx, uint64_t seed, int64_t first, int64_t n, int mode, uint8_t *d_out);
+
+/* ---- in-library HIP-event timing of the kernel classes (bench.py roofline) --------------------------------- */
+enum {
+    ICL_K_CONV = 0,       /* all implicit-GEMM conv launches */
+    ICL_K_DIST_EXACT = 1, /* exact Ward distance tile (K6x) */
+    ICL_K_DIST_MFMA = 2,  /* MFMA distance tile (K6) */
+    ICL_K_ROWMIN = 3,     /* masked row argmin scans (K7) */
+    ICL_K_UPDATE = 4,     /* per-merge exact row update (K8) */
+    ICL_K_EMBED_OTHER = 5,/* im2col, pooling, fc */
+    ICL_K_NCLASS = 6
+};
+int icl_prof_enable(icl_ctx *ctx, int on);
+int icl_prof_reset(icl_ctx *ctx);
+/* Accumulated since reset: device milliseconds, launches, algorithmic flops, algorithmic bytes. */
+int icl_prof_query(icl_ctx *ctx, int kclass, double *ms, int64_t *launches, double *flops, double *bytes);
+/* Stage wall times (ms, HIP events on the context stream) of the last embed / cluster call. */
+int icl_last_stage_ms(icl_ctx *ctx, double *embed_ms, double *dist_ms, double *merge_ms);
+
+const char *icl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,199 @@
+"""GPU parity tests of the Ward engine (imageclust_amd/csrc/ward.hip) against the CPU oracle, called through the
+C-ABI exactly as the reference's callers would use internal/clustering (clustering.go).  Bar: BIT-EXACT."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MAXF = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from imageclust_amd import _lib
+
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def CL(ctx):
+    from imageclust_amd import clustering
+
+    clustering.set_default_context(ctx)
+    return clustering
+
+
+def ids(n):
+    return ["a%d" % i for i in range(n)]
+
+
+def mog(n, d, seed, k=None, sigma=0.1):
+    rng = np.random.default_rng(seed)
+    k = k or max(1, n // 20)
+    cen = rng.standard_normal((k, d)).astype(np.float32)
+    lab = rng.integers(0, k, n)
+    return (cen[lab] + sigma * rng.standard_normal((n, d))).astype(np.float32)
+
+
+def same_as_oracle(ctx, E, mn, mx):
+    r = O.cluster(E, mn, mx, want_log=True)
+    cid, rank, nc = ctx.cluster(E, mn, mx)
+    assert r["ok"]
+    assert np.array_equal(cid, r["cluster_id"]), "cluster ids differ"
+    assert np.array_equal(rank, r["member_rank"]), "member order differs"
+    assert nc == r["n_clusters"]
+    m = ctx.last_merges()
+    assert len(m) == r["merges"]
+    assert np.array_equal(m, r["log"][:, 2:4].astype(np.int32)), "merge sequence differs"
+
+
+# ---- the reference-style known-answer tests through the mirrored API ------------------------
+def test_kat1(CL):
+    m, ok = CL.PerformClusteringWithConstraints([[0], [1], [3], [7], [8], [20]], ids(6), 1, 2)
+    assert ok and m == {0: ["a2"], 1: ["a5"], 2: ["a1", "a0"], 3: ["a4", "a3"]}
+
+
+def test_kat2_maxsize_skip(CL):
+    m, ok = CL.PerformClusteringWithConstraints([[0], [1], [2], [10]], ids(4), 2, 2)
+    assert ok and m == {0: ["a1", "a0"], 1: ["a3", "a2"]}
+
+
+def test_kat3_ban_sequence(CL):
+    m, ok = CL.PerformClusteringWithConstraints([[0], [1], [3], [7], [8], [20]], ids(6), 2, 2)
+    assert ok and m == {0: ["a1", "a0"], 1: ["a4", "a3"], 2: ["a5", "a2"]}
+
+
+def test_kat3b_minsize_drop(CL, ctx):
+    m, ok = CL.PerformClusteringWithConstraints([[0], [1], [2], [100]], ids(4), 2, 3)
+    assert ok and m == {0: ["a1", "a0", "a2"]}
+    cid, rank, nc = ctx.cluster(np.array([[0], [1], [2], [100]], np.float32), 2, 3)
+    assert cid.tolist() == [0, 0, 0, -1] and rank.tolist() == [1, 0, 2, -1] and nc == 1
+
+
+def test_kat4_constraint_errors(CL):
+    assert CL.PerformClusteringWithConstraints(np.zeros((2, 1)), ids(2), 3, 5) == (None, False)
+    assert CL.PerformClusteringWithConstraints(np.zeros((10, 1)), ids(10), 4, 4) == (None, False)
+    assert CL.PerformClusteringWithConstraints(np.zeros((10, 1)), ids(10), 0, 4) == (None, False)
+
+
+def test_kat5_optimal_clusters(CL):
+    assert CL.CalculateOptimalClusters(64, 3, 6) == (16, None)
+    assert CL.CalculateOptimalClusters(250000, 5, 50) == (27500, None)
+    assert CL.CalculateOptimalClusters(7, 1, 7) == (4, None)
+    assert CL.CalculateOptimalClusters(2, 3, 5)[1] is not None
+
+
+def test_kat6_find_closest(CL):
+    assert CL.FindClosestClusters(np.full((5, 5), MAXF, np.float32)) == (-1, -1)
+    assert CL.FindClosestClusters(np.zeros((1, 1), np.float32)) == (-1, -1)
+    D = np.full((4, 4), 5.0, np.float32)
+    D[2, 1] = np.nan
+    D[3, 0] = np.inf
+    D[3, 2] = 1.0
+    D[2, 0] = 1.0
+    D[0, 3] = -1.0  # upper triangle is never read
+    assert CL.FindClosestClusters(D) == (2, 0)
+
+
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 257, 700])
+def test_find_closest_matches_oracle_with_ties(ctx, n):
+    rng = np.random.default_rng(n)
+    D = rng.integers(0, 50, (n, n)).astype(np.float32)  # heavy ties
+    D[rng.random((n, n)) < 0.05] = np.nan
+    D[rng.random((n, n)) < 0.05] = MAXF
+    assert ctx.find_closest(D) == O.find_closest(D)
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (2, 1), (33, 17), (128, 64), (129, 1000), (300, 2048), (257, 6)])
+def test_kat7_distance_matrix_bit_exact(ctx, n, d):
+    rng = np.random.default_rng(n * 1000 + d)
+    E = rng.standard_normal((n, d)).astype(np.float32)
+    D = ctx.ward_distance_matrix(E)
+    R = O.initial_distance_matrix(E)
+    assert np.all(np.diag(D) == 0)
+    assert np.array_equal(D, D.T)
+    assert np.array_equal(D.view(np.uint32), R.view(np.uint32))
+    sizes = rng.integers(1, 60, n).astype(np.int32)
+    D2 = ctx.ward_distance_matrix(E, sizes)
+    R2 = O.initial_distance_matrix(E, sizes)
+    assert np.array_equal(D2.view(np.uint32), R2.view(np.uint32))
+
+
+def test_ward_distance_and_merge_helpers(CL):
+    rng = np.random.default_rng(5)
+    a = CL.Cluster([3, 1], 2, rng.standard_normal(300).astype(np.float32))
+    b = CL.Cluster([7], 5, rng.standard_normal(300).astype(np.float32))
+    assert CL.WardDistance(a, b) == O.ward_distance(a.Centroid, 2, b.Centroid, 5)
+    m = CL.MergeClusters(a, b)
+    assert m.Indices == [3, 1, 7] and m.Size == 7
+    assert np.array_equal(m.Centroid, O.merge_centroid(a.Centroid, 2, b.Centroid, 5))
+
+
+@pytest.mark.parametrize("n,d,mn,mx,seed", [(40, 8, 1, 40, 0), (64, 32, 3, 6, 20250217), (50, 4, 2, 5, 1), (30, 3, 1, 2, 2),
+                                            (25, 5, 5, 5, 3), (48, 16, 1, 3, 4), (200, 64, 3, 6, 5), (333, 2048, 5, 50, 6),
+                                            (130, 1000, 1, 130, 7), (2, 4, 1, 2, 8), (1, 4, 1, 1, 9), (65, 7, 1, 1, 10)])
+def test_cluster_bit_identical_to_oracle(ctx, n, d, mn, mx, seed):
+    same_as_oracle(ctx, mog(n, d, seed), mn, mx)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_cluster_exact_ties_and_duplicates(ctx, seed):
+    rng = np.random.default_rng(seed)
+    E = rng.integers(0, 4, (48, 4)).astype(np.float32)
+    for mn, mx in [(1, 48), (2, 6), (1, 2), (3, 4)]:
+        same_as_oracle(ctx, E, mn, mx)
+
+
+def test_cluster_all_identical_points(ctx):
+    same_as_oracle(ctx, np.ones((37, 5), np.float32), 2, 4)
+
+
+def test_cluster_nan_and_inf_rows(ctx):
+    E = mog(40, 6, 3)
+    E[7, 2] = np.nan
+    E[11, 0] = np.inf
+    same_as_oracle(ctx, E, 1, 3)
+
+
+def test_cluster_runs_out_of_pairs(ctx):
+    # max_size = 1: every pair is oversize -> the reference bans them all and breaks with len > k
+    E = mog(20, 3, 1)
+    r = O.cluster(E, 1, 1)
+    cid, rank, nc = ctx.cluster(E, 1, 1)
+    assert np.array_equal(cid, r["cluster_id"]) and nc == 20
+
+
+def test_cluster_mid_size_oracle_parity(ctx):
+    # ~1.3e9 scan steps in the literal oracle: a few seconds
+    same_as_oracle(ctx, mog(1200, 64, 42), 5, 50)
+
+
+def test_context_reuse_different_shapes(ctx):
+    for (n, d) in [(50, 8), (20, 16), (90, 4)]:
+        same_as_oracle(ctx, mog(n, d, n), 2, 6)
+
+
+def test_cluster_property_sizes_at_scale(ctx):
+    """Config-2-sized clustering (N=10000, D=2048): size-independent properties."""
+    E = mog(10000, 2048, 20250217, k=500)
+    cid, rank, nc = ctx.cluster(E, 5, 50)
+    kept = cid[cid >= 0]
+    counts = np.bincount(kept)
+    assert sorted(set(kept.tolist())) == list(range(nc))
+    assert counts.min() >= 5 and counts.max() <= 50
+    # ranks inside each cluster are a permutation of 0..size-1
+    order = np.lexsort((rank, cid))
+    o = order[cid[order] >= 0]
+    starts = np.r_[0, np.cumsum(counts)[:-1]]
+    assert np.array_equal(rank[o], np.arange(len(o)) - np.repeat(starts, counts))
+    m = ctx.last_merges()
+    assert len(m) == 10000 - 1100  # k = CalculateOptimalClusters(10000,5,50) = 1100
+    # every merge joins two live clusters; ids are creation ids
+    assert (m[:, 0] != m[:, 1]).all() and m.max() < 10000 + len(m)
+    # idempotence: same input -> same result
+    cid2, rank2, _ = ctx.cluster(E, 5, 50)
+    assert np.array_equal(cid, cid2) and np.array_equal(rank, rank2)
