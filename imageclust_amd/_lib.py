@@ -46,6 +46,7 @@ SYMBOLS = [
     ("icl_embed_file", _int, [_vp, C.c_char_p, _int, _vp]),
     ("icl_preprocess_u8", _int, [_vp, _vp]),
     ("icl_set_batch", _int, [_vp, _int]),
+    ("icl_conv2d_fused", _int, [_vp, _int, _vp, _int, _int, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _int, _vp]),
     ("icl_calc_optimal_clusters", _int, [_i64, _i64, _i64, _pi64]),
     ("icl_ward_distance_matrix", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
     ("icl_ward_distance_matrix_dev", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
@@ -207,6 +208,21 @@ class Context:
         out = np.empty(head, np.float32)
         check(self.h, self.L.icl_embed_file(self.h, os.fsencode(path), head, out.ctypes.data))
         return out
+
+    def conv2d_fused(self, x_nhwc, w_oihw, scale, shift, stride=1, pad=0, residual=None, relu=True, prec=PREC_FP32):
+        x = np.ascontiguousarray(x_nhwc, np.float32)
+        w = np.ascontiguousarray(w_oihw, np.float32)
+        B, H, _, Cin = x.shape
+        Cout, _, k, _ = w.shape
+        Ho = (H + 2 * pad - k) // stride + 1
+        y = np.empty((B, Ho, Ho, Cout), np.float32)
+        sc = np.ascontiguousarray(scale, np.float32)
+        sh = np.ascontiguousarray(shift, np.float32)
+        r = None if residual is None else np.ascontiguousarray(residual, np.float32)
+        check(self.h, self.L.icl_conv2d_fused(self.h, prec, x.ctypes.data, B, H, Cin, w.ctypes.data, Cout, k, stride, pad,
+                                              sc.ctypes.data, sh.ctypes.data, None if r is None else r.ctypes.data,
+                                              1 if relu else 0, y.ctypes.data))
+        return y
 
     def synth_images_dev(self, seed, first, n, mode, d_out):
         check(self.h, self.L.icl_synth_images_dev(self.h, seed, first, n, mode, _vp(d_out)))

@@ -1,12 +1,920 @@
+// resnet.hip -- hand-written ResNet50-v1 forward for gfx950: the embedding half of the hot path.
+//
+// Replaces LoadPretrainedModelONNX / PreprocessImage / GetImageEmbedding
+//   (/root/reference/internal/embeddings/embeddings.go:28-43, :46-116, :119-163), i.e. the OpenCV-DNN forward
+// of resnet50-v1-7.onnx that the reference reaches through gocv (batch 1, CPU, serialised by NetMutex :133).
+//
+// Layout: activations NHWC (channels contiguous) in bf16 (throughput) or f32 (parity); weights re-packed once
+// at load to [Cout][KH][KW][Cin] so every implicit-GEMM K-chunk is a contiguous run of input channels of ONE
+// filter tap.  Every convolution is one launch of conv_igemm_kernel: a 128(pixels) x BN(channels) output tile
+// per 256-thread workgroup, K staged through XOR-swizzled LDS in 64-byte row chunks, v_mfma_f32_32x32x16_bf16
+// (or v_mfma_f32_32x32x2_f32 in parity mode) with the WEIGHTS as the MFMA A operand so that each lane ends up
+// holding 4 consecutive output channels of one pixel -> contiguous NHWC stores; BatchNorm (folded to
+// scale/shift), conv bias, residual add and ReLU are fused into the epilogue.  The 7x7/2 stem is lowered to the
+// same kernel through an im2col of the u8 image (K = 147 padded to 160), which also performs the reference's
+// RGB/255 scaling (embeddings.go:96).
 #include "icl_common.h"
-void icl_model_free(icl_ctx *ctx) {}
-#define STUB(sig) extern "C" int sig { return icl_fail(nullptr, ICL_ERR_UNSUPPORTED, "not built yet"); }
-STUB(icl_model_load_onnx(icl_ctx *, const char *))
-STUB(icl_model_load_blob(icl_ctx *, const void *, int64_t))
-STUB(icl_model_load_synthetic(icl_ctx *, uint64_t))
-extern "C" int64_t icl_synthetic_blob_bytes(void) { return 0; }
-STUB(icl_synthetic_blob(uint64_t, void *, int64_t))
-STUB(icl_embed_u8(icl_ctx *, const uint8_t *, int64_t, int, int, float *))
-STUB(icl_embed_u8_dev(icl_ctx *, const uint8_t *, int64_t, int, int, float *))
-STUB(icl_embed_file(icl_ctx *, const char *, int, float *))
-STUB(icl_preprocess_u8(const uint8_t *, float *))
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------------------
+// element traits
+// ------------------------------------------------------------------------------------------------------------
+struct BF16 {
+    typedef uint16_t elem;
+    static constexpr int KE = 8;  // elements per 16-byte chunk
+    static constexpr int BK = 32; // elements per 64-byte LDS row
+    __device__ static __forceinline__ float to_f(elem v) { return __uint_as_float((uint32_t)v << 16); }
+    __device__ static __forceinline__ elem from_f(float f)
+    {
+        // round to nearest even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (elem)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (elem)(u >> 16);
+    }
+    __device__ static __forceinline__ void mma(const uint4 &w, const uint4 &x, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+    }
+};
+struct F32 {
+    typedef float elem;
+    static constexpr int KE = 4;
+    static constexpr int BK = 16;
+    __device__ static __forceinline__ float to_f(elem v) { return v; }
+    __device__ static __forceinline__ elem from_f(float f) { return f; }
+    __device__ static __forceinline__ void mma(const uint4 &w, const uint4 &x, f32x16 &acc)
+    {
+        // lane half h holds k = 4h..4h+3 of this 8-deep slice; MFMA q pairs k=q (h=0) with k=4+q (h=1) on both operands
+        const float4 wf = __builtin_bit_cast(float4, w), xf = __builtin_bit_cast(float4, x);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, xf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, xf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.z, xf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.w, xf.w, acc, 0, 0, 0);
+    }
+};
+
+struct conv_args {
+    const void *X;      // [B][H][W][Cin]
+    const void *Wt;     // [Cout][KH][KW][Cin]
+    void *Y;            // [B][Ho][Wo][Cout]
+    const void *R;      // residual, same shape as Y, or nullptr
+    const float *scale; // [Cout] folded BN scale
+    const float *shift; // [Cout] folded BN shift (+ conv bias)
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int64_t M;          // B*Ho*Wo
+    int K;              // KH*KW*Cin
+};
+
+#define CV_BM 128
+
+// LDS image of a [rows][64 B] tile: 16-byte slot s of row r lives at r*64 + ((s ^ ((r>>2)&3)) * 16).
+// A ds_read_b128 lane group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row fragment, same logical slot)
+// then touches 16 distinct 16-byte bank slots: conflict-free (MI355X_MICROARCH.md "LDS").
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
+{
+    typedef typename T::elem elem;
+    constexpr int NT = BN / 64;        // 32-channel MFMA row tiles per wave
+    constexpr int WCH = BN / 64;       // weight chunks per thread per k-step (BN rows x 4 slots / 256)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BN + CV_BM) * 64];
+    constexpr int STAGE = (BN + CV_BM) * 64; // one pipeline stage: BN weight rows then CV_BM activation rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1;
+    const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
+    const int n0 = blockIdx.y * BN;
+    const elem *Xg = (const elem *)p.X;
+    const elem *Wg = (const elem *)p.Wt;
+
+    // ---- per-thread staging roles (fixed for the whole K loop) ----
+    // activations: 2 chunks: rows (tid>>2) and 64+(tid>>2), slot tid&3
+    const int xslot = tid & 3;
+    int xrow[2];
+    int64_t xbase[2]; // element offset of pixel (b, oy*stride-pad, ox*stride-pad), channel 0
+    int xiy[2], xix[2];
+    bool xok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        xrow[i] = (tid >> 2) + 64 * i;
+        const int64_t m = m0 + xrow[i];
+        xok[i] = m < p.M;
+        const int64_t mm = xok[i] ? m : 0;
+        const int ox = (int)(mm % p.Wo);
+        const int64_t t = mm / p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        xiy[i] = oy * p.stride - p.pad;
+        xix[i] = ox * p.stride - p.pad;
+        xbase[i] = (((int64_t)b * p.H + xiy[i]) * p.W + xix[i]) * p.Cin;
+    }
+    // weights: WCH chunks: rows (tid>>2) + 64*i, slot tid&3
+    const int64_t wbase = (int64_t)(n0 + (tid >> 2)) * p.K + xslot * T::KE;
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    uint4 xr[2], wr[WCH];
+    int kh = 0, kw = 0, ci0 = 0, k0 = 0; // position of the k-step being LOADED
+    auto gload = [&]() {
+        const int64_t tap_off = ((int64_t)kh * p.W + kw) * p.Cin + ci0 + xslot * T::KE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = xok[i] && (unsigned)(xiy[i] + kh) < (unsigned)p.H && (unsigned)(xix[i] + kw) < (unsigned)p.W;
+            xr[i] = ok ? *reinterpret_cast<const uint4 *>(Xg + xbase[i] + tap_off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) wr[i] = *reinterpret_cast<const uint4 *>(Wg + wbase + (int64_t)i * 64 * p.K + k0);
+        // advance to the next k-step (uniform)
+        k0 += T::BK;
+        ci0 += T::BK;
+        if (ci0 == p.Cin) {
+            ci0 = 0;
+            if (++kw == p.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(smem + buf * STAGE + BN * 64 + lds_off(xrow[i], xslot)) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4 *>(smem + buf * STAGE + lds_off((tid >> 2) + 64 * i, xslot)) = wr[i];
+    };
+
+    const int nk = p.K / T::BK;
+    gload();
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) gload();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 wf[NT], xf[2];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4 *>(smem + cur * STAGE + lds_off(wn * (BN / 2) + a * 32 + fr, 2 * s + fh));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4 *>(smem + cur * STAGE + BN * 64 + lds_off(wm * 64 + b * 32 + fr, 2 * s + fh));
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) T::mma(wf[a], xf[b], acc[a][b]);
+        }
+        if (ks + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = relu(acc*scale + shift (+ residual)) ; lane = pixel, 4 consecutive channels per store ----
+    elem *Yg = (elem *)p.Y;
+    const elem *Rg = (const elem *)p.R;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t m = m0 + wm * 64 + b * 32 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
+                const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
+                const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
+                float v[4] = {acc[a][b][4 * g + 0] * sc.x + sh.x, acc[a][b][4 * g + 1] * sc.y + sh.y,
+                              acc[a][b][4 * g + 2] * sc.z + sh.z, acc[a][b][4 * g + 3] * sc.w + sh.w};
+                const int64_t off = m * p.Cout + n;
+                if (Rg) {
+                    if constexpr (sizeof(elem) == 2) {
+                        const uint2 rv = *reinterpret_cast<const uint2 *>(Rg + off);
+                        v[0] += T::to_f((elem)(rv.x & 0xffffu));
+                        v[1] += T::to_f((elem)(rv.x >> 16));
+                        v[2] += T::to_f((elem)(rv.y & 0xffffu));
+                        v[3] += T::to_f((elem)(rv.y >> 16));
+                    } else {
+                        const float4 rv = *reinterpret_cast<const float4 *>(Rg + off);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+                }
+                if constexpr (sizeof(elem) == 2) {
+                    uint2 o;
+                    o.x = (uint32_t)T::from_f(v[0]) | ((uint32_t)T::from_f(v[1]) << 16);
+                    o.y = (uint32_t)T::from_f(v[2]) | ((uint32_t)T::from_f(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(Yg + off) = o;
+                } else {
+                    *reinterpret_cast<float4 *>(Yg + off) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1 + stem lowering: u8 HWC RGB -> im2col rows [B*112*112][160] (k = (kh*7+kw)*3+c, zero padded), scaled by
+// float(1/255) exactly as BlobFromImage(scalefactor=1/255) does (embeddings.go:96).
+// ------------------------------------------------------------------------------------------------------------
+#define STEM_K 160
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const uint8_t *__restrict__ img, int B, typename T::elem *__restrict__ out)
+{
+    typedef typename T::elem elem;
+    constexpr int CH = STEM_K / T::KE; // 16-byte chunks per row
+    const int64_t total = (int64_t)B * 112 * 112 * CH;
+    const float sc = (float)(1.0 / 255.0);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % CH);
+        const int64_t m = t / CH;
+        const int ox = (int)(m % 112), oy = (int)((m / 112) % 112), b = (int)(m / (112 * 112));
+        elem v[T::KE];
+#pragma unroll
+        for (int e = 0; e < T::KE; ++e) {
+            const int k = ch * T::KE + e;
+            float f = 0.0f;
+            if (k < 147) {
+                const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
+                const int iy = oy * 2 - 3 + kh, ix = ox * 2 - 3 + kw;
+                if ((unsigned)iy < 224u && (unsigned)ix < 224u)
+                    f = (float)img[(((int64_t)b * 224 + iy) * 224 + ix) * 3 + c] * sc;
+            }
+            v[e] = T::from_f(f);
+        }
+        *reinterpret_cast<uint4 *>(out + m * STEM_K + ch * T::KE) = *reinterpret_cast<const uint4 *>(v);
+    }
+}
+
+// MaxPool 3x3/2 p1 (padding never wins), NHWC, one thread per 16-byte channel chunk of one output pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const typename T::elem *__restrict__ in, int B, int H, int C,
+                                                     typename T::elem *__restrict__ out)
+{
+    typedef typename T::elem elem;
+    const int Ho = H / 2, CH = C / T::KE;
+    const int64_t total = (int64_t)B * Ho * Ho * CH;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % CH);
+        const int64_t m = t / CH;
+        const int ox = (int)(m % Ho), oy = (int)((m / Ho) % Ho), b = (int)(m / ((int64_t)Ho * Ho));
+        float best[T::KE];
+#pragma unroll
+        for (int e = 0; e < T::KE; ++e) best[e] = -INFINITY;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
+                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)H) continue;
+                const uint4 raw = *reinterpret_cast<const uint4 *>(in + (((int64_t)b * H + iy) * H + ix) * C + ch * T::KE);
+                const elem *pv = reinterpret_cast<const elem *>(&raw);
+#pragma unroll
+                for (int e = 0; e < T::KE; ++e) {
+                    const float f = T::to_f(pv[e]);
+                    if (f > best[e]) best[e] = f;
+                }
+            }
+        elem o[T::KE];
+#pragma unroll
+        for (int e = 0; e < T::KE; ++e) o[e] = T::from_f(best[e]);
+        *reinterpret_cast<uint4 *>(out + m * C + ch * T::KE) = *reinterpret_cast<const uint4 *>(o);
+    }
+}
+
+// GlobalAveragePool over HW positions -> fp32 [B][C] (sequential fp32 sum, then / HW).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const typename T::elem *__restrict__ in, int B, int HW, int C,
+                                                     float *__restrict__ out, int64_t out_ld)
+{
+    const int64_t total = (int64_t)B * C;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        float s = 0.0f;
+        for (int i = 0; i < HW; ++i) s += T::to_f(in[(b * HW + i) * C + c]);
+        out[b * out_ld + c] = s / (float)HW;
+    }
+}
+
+// dense0: y[b][o] = sum_i x[b][i] * W[o][i] + bias[o]; one wave per output, fp32.
+__global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
+                                                int B, int nin, int nout, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = wave; t < (int64_t)B * nout; t += nw) {
+        const int o = (int)(t % nout);
+        const int64_t b = t / nout;
+        float s = 0.0f;
+        for (int i = lane * 4; i < nin; i += 256) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + b * nin + i);
+            const float4 wv = *reinterpret_cast<const float4 *>(W + (int64_t)o * nin + i);
+            s += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) y[b * nout + o] = s + bias[o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// model (host)
+// ------------------------------------------------------------------------------------------------------------
+struct conv_layer {
+    icl_conv_rec rec;
+    int K = 0, cin_eff = 0; // cin_eff: channel count seen by the kernel (160 for the lowered stem)
+    void *w[2] = {nullptr, nullptr}; // [ICL_PREC_FP32], [ICL_PREC_BF16]
+    float *scale = nullptr, *shift = nullptr;
+};
+
+struct icl_model {
+    conv_layer conv[ICL_RESNET50_NCONV];
+    int nconv = 0;
+    float *fcw = nullptr, *fcb = nullptr;
+    // activation workspace
+    void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *im2col = nullptr;
+    float *pooled = nullptr;
+    int ws_batch = 0, ws_prec = -1;
+};
+
+static int resnet50_topology(icl_conv_rec *out)
+{
+    static const int nblocks[4] = {3, 4, 6, 3};
+    int n = 0;
+    out[n++] = icl_conv_rec{3, 64, 7, 2, 3, 224, 112, 0, 0, 0};
+    int h = 56, cin = 64;
+    for (int s = 0; s < 4; ++s) {
+        const int cout = 256 << s, mid = cout / 4;
+        for (int b = 0; b < nblocks[s]; ++b) {
+            const int stride = (b == 0 && s > 0) ? 2 : 1, ho = h / stride;
+            out[n++] = icl_conv_rec{cin, mid, 1, stride, 0, h, ho, 1, s + 1, b};
+            out[n++] = icl_conv_rec{mid, mid, 3, 1, 1, ho, ho, 2, s + 1, b};
+            out[n++] = icl_conv_rec{mid, cout, 1, 1, 0, ho, ho, 3, s + 1, b};
+            if (b == 0) out[n++] = icl_conv_rec{cin, cout, 1, stride, 0, h, ho, 4, s + 1, b};
+            cin = cout;
+            h = ho;
+        }
+    }
+    return n;
+}
+
+static int64_t blob_floats(const icl_blob_header &h)
+{
+    icl_conv_rec t[ICL_RESNET50_NCONV];
+    const int n = resnet50_topology(t);
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        tot += (int64_t)t[i].cout * t[i].cin * t[i].k * t[i].k + 4 * (int64_t)t[i].cout;
+        if (h.has_bias[i]) tot += t[i].cout;
+    }
+    return tot + (int64_t)ICL_FC_OUT * ICL_FEAT_DIM + ICL_FC_OUT;
+}
+
+static void default_header(icl_blob_header &h)
+{
+    memset(&h, 0, sizeof h);
+    h.magic = ICL_BLOB_MAGIC;
+    h.version = ICL_BLOB_VERSION;
+    h.bn_eps = 1e-5f;
+    h.n_conv = ICL_RESNET50_NCONV;
+    icl_conv_rec t[ICL_RESNET50_NCONV];
+    const int n = resnet50_topology(t);
+    // Gluon resnet50_v1: the bottleneck's 1x1 convs carry a bias, 3x3 / stem / downsample do not
+    for (int i = 0; i < n; ++i) h.has_bias[i] = (t[i].role == 1 || t[i].role == 3) ? 1 : 0;
+}
+
+extern "C" int64_t icl_synthetic_blob_bytes(void)
+{
+    icl_blob_header h;
+    default_header(h);
+    return (int64_t)sizeof(h) + 4 * blob_floats(h);
+}
+
+// counter-based generator: element e of the blob draws from splitmix64(seed, e)
+struct synth_rng {
+    uint64_t seed, ctr = 0;
+    double uni() { return (double)(icl_splitmix64(seed ^ (0xD1B54A32D192ED03ull * ++ctr)) >> 11) * (1.0 / 9007199254740992.0); }
+    double normal()
+    {
+        const double u1 = uni(), u2 = uni();
+        return std::sqrt(-2.0 * std::log(u1 > 1e-300 ? u1 : 1e-300)) * std::cos(6.283185307179586476925 * u2);
+    }
+};
+
+extern "C" int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes)
+{
+    if (!blob || bytes != icl_synthetic_blob_bytes()) return icl_fail(nullptr, ICL_ERR_ARG, "icl_synthetic_blob: need a %lld-byte buffer", (long long)icl_synthetic_blob_bytes());
+    icl_blob_header h;
+    default_header(h);
+    memcpy(blob, &h, sizeof h);
+    float *p = (float *)((char *)blob + sizeof h);
+    icl_conv_rec t[ICL_RESNET50_NCONV];
+    const int n = resnet50_topology(t);
+    synth_rng g{seed};
+    for (int i = 0; i < n; ++i) {
+        const int64_t nw = (int64_t)t[i].cout * t[i].cin * t[i].k * t[i].k;
+        const double sd = std::sqrt(2.0 / ((double)t[i].cin * t[i].k * t[i].k)); // He init
+        for (int64_t e = 0; e < nw; ++e) *p++ = (float)(sd * g.normal());
+        if (h.has_bias[i])
+            for (int c = 0; c < t[i].cout; ++c) *p++ = (float)(0.01 * g.normal());
+        for (int c = 0; c < t[i].cout; ++c) *p++ = (float)(0.5 + g.uni());      // gamma ~ U(0.5,1.5)
+        for (int c = 0; c < t[i].cout; ++c) *p++ = (float)(0.1 * g.normal());   // beta
+        for (int c = 0; c < t[i].cout; ++c) *p++ = (float)(0.1 * g.normal());   // running mean
+        for (int c = 0; c < t[i].cout; ++c) *p++ = (float)(0.5 + g.uni());      // running var ~ U(0.5,1.5)
+    }
+    const double fsd = std::sqrt(1.0 / ICL_FEAT_DIM);
+    for (int64_t e = 0; e < (int64_t)ICL_FC_OUT * ICL_FEAT_DIM; ++e) *p++ = (float)(fsd * g.normal());
+    for (int e = 0; e < ICL_FC_OUT; ++e) *p++ = 0.0f;
+    return ICL_OK;
+}
+
+static inline uint16_t host_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+void icl_model_free(icl_ctx *ctx)
+{
+    icl_model *m = ctx->model;
+    if (!m) return;
+    for (auto &c : m->conv) {
+        for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift})
+            if (p) (void)hipFree(p);
+    }
+    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], m->im2col, (void *)m->pooled})
+        if (p) (void)hipFree(p);
+    delete m;
+    ctx->model = nullptr;
+}
+
+static int upload(icl_ctx *ctx, void **dst, const void *src, size_t bytes)
+{
+    ICL_HIP(ctx, hipMalloc(dst, bytes));
+    ICL_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return ICL_OK;
+}
+
+extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes)
+{
+    if (!ctx || !blob) return icl_fail(ctx, ICL_ERR_ARG, "icl_model_load_blob: bad argument");
+    if (bytes < (int64_t)sizeof(icl_blob_header)) return icl_fail(ctx, ICL_ERR_IO, "weight blob too small");
+    icl_blob_header h;
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != ICL_BLOB_MAGIC || h.version != ICL_BLOB_VERSION || h.n_conv != ICL_RESNET50_NCONV)
+        return icl_fail(ctx, ICL_ERR_IO, "not an ICLW v%u ResNet50 blob", ICL_BLOB_VERSION);
+    if (bytes != (int64_t)sizeof h + 4 * blob_floats(h))
+        return icl_fail(ctx, ICL_ERR_IO, "weight blob has %lld bytes, expected %lld", (long long)bytes, (long long)(sizeof h + 4 * blob_floats(h)));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    icl_model_free(ctx);
+    icl_model *m = new icl_model();
+    ctx->model = m;
+    icl_conv_rec t[ICL_RESNET50_NCONV];
+    m->nconv = resnet50_topology(t);
+    const float *p = (const float *)((const char *)blob + sizeof h);
+    std::vector<float> wf;
+    std::vector<uint16_t> wb;
+    std::vector<float> sc, sh;
+    for (int i = 0; i < m->nconv; ++i) {
+        conv_layer &L = m->conv[i];
+        L.rec = t[i];
+        const int cin = t[i].cin, cout = t[i].cout, k = t[i].k;
+        const float *W = p;
+        p += (int64_t)cout * cin * k * k;
+        const float *bias = nullptr;
+        if (h.has_bias[i]) {
+            bias = p;
+            p += cout;
+        }
+        const float *gamma = p, *beta = p + cout, *mean = p + 2 * cout, *var = p + 3 * cout;
+        p += 4 * (int64_t)cout;
+        // re-pack OIHW -> [cout][kh][kw][cin] (stem: K padded 147 -> 160)
+        L.cin_eff = (i == 0) ? STEM_K : cin;
+        L.K = (i == 0) ? STEM_K : cin * k * k;
+        wf.assign((size_t)cout * L.K, 0.0f);
+        for (int co = 0; co < cout; ++co)
+            for (int c = 0; c < cin; ++c)
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < k; ++b)
+                        wf[(size_t)co * L.K + ((size_t)a * k + b) * cin + c] = W[(((size_t)co * cin + c) * k + a) * k + b];
+        wb.resize(wf.size());
+        for (size_t e = 0; e < wf.size(); ++e) wb[e] = host_bf16(wf[e]);
+        ICL_TRY(upload(ctx, &L.w[ICL_PREC_FP32], wf.data(), wf.size() * 4));
+        ICL_TRY(upload(ctx, &L.w[ICL_PREC_BF16], wb.data(), wb.size() * 2));
+        // BatchNormalization folded to y = x*scale + shift, conv bias folded into shift
+        sc.resize(cout);
+        sh.resize(cout);
+        for (int c = 0; c < cout; ++c) {
+            const double s = (double)gamma[c] / std::sqrt((double)var[c] + (double)h.bn_eps);
+            sc[c] = (float)s;
+            sh[c] = (float)((double)beta[c] - (double)mean[c] * s + (bias ? (double)bias[c] * s : 0.0));
+        }
+        ICL_TRY(upload(ctx, (void **)&L.scale, sc.data(), (size_t)cout * 4));
+        ICL_TRY(upload(ctx, (void **)&L.shift, sh.data(), (size_t)cout * 4));
+    }
+    ICL_TRY(upload(ctx, (void **)&m->fcw, p, (size_t)ICL_FC_OUT * ICL_FEAT_DIM * 4));
+    p += (int64_t)ICL_FC_OUT * ICL_FEAT_DIM;
+    ICL_TRY(upload(ctx, (void **)&m->fcb, p, (size_t)ICL_FC_OUT * 4));
+    return ICL_OK;
+}
+
+extern "C" int icl_model_load_synthetic(icl_ctx *ctx, uint64_t seed)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    const int64_t nb = icl_synthetic_blob_bytes();
+    std::vector<char> blob((size_t)nb);
+    ICL_TRY(icl_synthetic_blob(seed, blob.data(), nb));
+    return icl_model_load_blob(ctx, blob.data(), nb);
+}
+
+extern "C" int icl_model_load_onnx(icl_ctx *ctx, const char *path)
+{
+    // LoadPretrainedModelONNX (embeddings.go:28-43).  The ONNX initializer reader is SURVEY.md 8f-1 ("next").
+    if (!ctx || !path) return icl_fail(ctx, ICL_ERR_ARG, "icl_model_load_onnx: bad argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s", path); // embeddings.go:32
+    fclose(f);
+    return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "ONNX initializer reader not built yet (SURVEY.md 8f-1); convert the model to an ICLW blob");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------
+static int ensure_ws(icl_ctx *ctx, int batch, int prec)
+{
+    icl_model *m = ctx->model;
+    if (m->ws_batch >= batch && m->ws_prec == prec) return ICL_OK;
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &b : m->buf)
+        if (b) {
+            (void)hipFree(b);
+            b = nullptr;
+        }
+    if (m->im2col) (void)hipFree(m->im2col);
+    if (m->pooled) (void)hipFree(m->pooled);
+    m->im2col = nullptr;
+    m->pooled = nullptr;
+    m->ws_batch = 0;
+    const size_t es = prec == ICL_PREC_BF16 ? 2 : 4;
+    const size_t act = (size_t)batch * 802816 * es; // 112*112*64 == 56*56*256: the largest activation
+    for (auto &b : m->buf) {
+        hipError_t e = hipMalloc(&b, act);
+        if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "activation workspace (%zu B): %s", act, hipGetErrorString(e));
+    }
+    hipError_t e = hipMalloc(&m->im2col, (size_t)batch * 12544 * STEM_K * es);
+    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "im2col workspace: %s", hipGetErrorString(e));
+    ICL_HIP(ctx, hipMalloc((void **)&m->pooled, (size_t)batch * ICL_FEAT_DIM * 4));
+    m->ws_batch = batch;
+    m->ws_prec = prec;
+    return ICL_OK;
+}
+
+template <typename T>
+static int launch_conv_t(icl_ctx *ctx, const conv_args &a)
+{
+    const unsigned gx = (unsigned)icl_ceil_div(a.M, CV_BM);
+    icl_prof_scope ps(ctx, ICL_K_CONV, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    if (a.Cout % 128 == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(gx, a.Cout / 128), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(gx, a.Cout / 64), dim3(256), 0, ctx->stream, a);
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}
+
+static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *X, void *Y, const void *R, int relu, int B,
+                       bool lowered_stem)
+{
+    conv_args a;
+    a.X = X;
+    a.Wt = L.w[prec];
+    a.Y = Y;
+    a.R = R;
+    a.scale = L.scale;
+    a.shift = L.shift;
+    a.B = B;
+    a.relu = relu;
+    a.Cout = L.rec.cout;
+    if (lowered_stem) { // im2col rows as a 1x1 convolution over a 112x112x160 "image"
+        a.H = a.W = a.Ho = a.Wo = 112;
+        a.Cin = STEM_K;
+        a.KH = a.KW = 1;
+        a.stride = 1;
+        a.pad = 0;
+    } else {
+        a.H = a.W = L.rec.hin;
+        a.Ho = a.Wo = L.rec.hout;
+        a.Cin = L.rec.cin;
+        a.KH = a.KW = L.rec.k;
+        a.stride = L.rec.stride;
+        a.pad = L.rec.pad;
+    }
+    a.M = (int64_t)B * a.Ho * a.Wo;
+    a.K = a.KH * a.KW * a.Cin;
+    const int bk = prec == ICL_PREC_BF16 ? BF16::BK : F32::BK;
+    if (a.Cin % bk || a.Cout % 64 || a.K != L.K)
+        return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "conv shape cin=%d cout=%d k=%d not supported by the implicit-GEMM kernel", a.Cin, a.Cout, a.KH);
+    return prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
+}
+
+static inline float host_from_bf16(uint16_t v)
+{
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int Cin, const float *w, int Cout, int k,
+                                int stride, int pad, const float *scale, const float *shift, const float *residual, int relu, float *y)
+{
+    if (!ctx || !x || !w || !scale || !shift || !y || B < 1 || H < 1 || k < 1 || stride < 1 || pad < 0)
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_conv2d_fused: bad argument");
+    if (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) return icl_fail(ctx, ICL_ERR_ARG, "bad prec");
+    if (Cin % 32 || Cout % 64) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_conv2d_fused needs Cin %% 32 == 0 and Cout %% 64 == 0");
+    const int Ho = (H + 2 * pad - k) / stride + 1;
+    if (Ho < 1) return icl_fail(ctx, ICL_ERR_ARG, "empty output");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    const size_t es = prec == ICL_PREC_BF16 ? 2 : 4;
+    const size_t nx = (size_t)B * H * H * Cin, nw = (size_t)Cout * Cin * k * k, ny = (size_t)B * Ho * Ho * Cout;
+    std::vector<float> wp(nw);
+    for (int co = 0; co < Cout; ++co)
+        for (int c = 0; c < Cin; ++c)
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) wp[(size_t)co * Cin * k * k + ((size_t)a * k + b) * Cin + c] = w[(((size_t)co * Cin + c) * k + a) * k + b];
+    auto to_dev = [&](const float *src, size_t n, void **dst) -> int {
+        ICL_HIP(ctx, hipMalloc(dst, n * es));
+        if (prec == ICL_PREC_BF16) {
+            std::vector<uint16_t> t(n);
+            for (size_t i = 0; i < n; ++i) t[i] = host_bf16(src[i]);
+            ICL_HIP(ctx, hipMemcpy(*dst, t.data(), n * 2, hipMemcpyHostToDevice));
+        } else {
+            ICL_HIP(ctx, hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+        }
+        return ICL_OK;
+    };
+    void *dx = nullptr, *dw = nullptr, *dr = nullptr, *dy = nullptr;
+    float *dsc = nullptr, *dsh = nullptr;
+    int rc = to_dev(x, nx, &dx);
+    if (!rc) rc = to_dev(wp.data(), nw, &dw);
+    if (!rc && residual) rc = to_dev(residual, ny, &dr);
+    if (!rc) rc = upload(ctx, (void **)&dsc, scale, (size_t)Cout * 4);
+    if (!rc) rc = upload(ctx, (void **)&dsh, shift, (size_t)Cout * 4);
+    if (!rc && hipMalloc(&dy, ny * es) != hipSuccess) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_conv2d_fused: output alloc");
+    if (!rc) {
+        conv_args a;
+        a.X = dx; a.Wt = dw; a.Y = dy; a.R = dr; a.scale = dsc; a.shift = dsh;
+        a.B = B; a.H = a.W = H; a.Cin = Cin; a.Ho = a.Wo = Ho; a.Cout = Cout; a.KH = a.KW = k; a.stride = stride; a.pad = pad;
+        a.relu = relu; a.M = (int64_t)B * Ho * Ho; a.K = k * k * Cin;
+        rc = prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
+    }
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            if (prec == ICL_PREC_BF16) {
+                std::vector<uint16_t> t(ny);
+                e = hipMemcpy(t.data(), dy, ny * 2, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < ny; ++i) y[i] = host_from_bf16(t[i]);
+            } else {
+                e = hipMemcpy(y, dy, ny * 4, hipMemcpyDeviceToHost);
+            }
+        }
+        if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_conv2d_fused: %s", hipGetErrorString(e));
+    }
+    for (void *q : {dx, dw, dr, dy, (void *)dsc, (void *)dsh})
+        if (q) (void)hipFree(q);
+    icl_prof_collect(ctx);
+    return rc;
+}
+
+template <typename T>
+static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, int head, float *d_out)
+{
+    typedef typename T::elem elem;
+    icl_model *m = ctx->model;
+    const int grid = 256 * 8;
+    elem *x = (elem *)m->buf[0], *t1 = (elem *)m->buf[1], *t2 = (elem *)m->buf[2], *ds = (elem *)m->buf[3], *y = (elem *)m->buf[4];
+    {
+        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (ICL_IMG_BYTES + 12544.0 * STEM_K * sizeof(elem)));
+        hipLaunchKernelGGL((stem_im2col_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, d_img, B, (elem *)m->im2col);
+    }
+    ICL_TRY(launch_conv(ctx, prec, m->conv[0], m->im2col, y, nullptr, 1, B, true));
+    {
+        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
+        hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, y, B, 112, 64, x);
+    }
+    int ci = 1;
+    while (ci < m->nconv) {
+        const conv_layer &c1 = m->conv[ci], &c2 = m->conv[ci + 1], &c3 = m->conv[ci + 2];
+        const bool has_ds = c1.rec.block == 0;
+        ICL_TRY(launch_conv(ctx, prec, c1, x, t1, nullptr, 1, B, false));
+        ICL_TRY(launch_conv(ctx, prec, c2, t1, t2, nullptr, 1, B, false));
+        const void *res = x;
+        if (has_ds) {
+            ICL_TRY(launch_conv(ctx, prec, m->conv[ci + 3], x, ds, nullptr, 0, B, false));
+            res = ds;
+        }
+        ICL_TRY(launch_conv(ctx, prec, c3, t2, y, res, 1, B, false)); // relu(bn(conv) + residual)
+        std::swap(x, y);
+        ci += has_ds ? 4 : 3;
+    }
+    float *pooled = head == ICL_HEAD_POOLED ? d_out : m->pooled;
+    {
+        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * 49.0 * 2048.0 * sizeof(elem));
+        hipLaunchKernelGGL((avgpool_kernel<T>), dim3((unsigned)icl_ceil_div((int64_t)B * 2048, 256)), dim3(256), 0, ctx->stream, x, B, 49,
+                           ICL_FEAT_DIM, pooled, (int64_t)ICL_FEAT_DIM);
+    }
+    if (head == ICL_HEAD_DENSE0) {
+        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 2.0 * B * 2048.0 * 1000.0, 0.0);
+        hipLaunchKernelGGL(fc_kernel, dim3((unsigned)std::min<int64_t>(icl_ceil_div((int64_t)B * ICL_FC_OUT, 4), 4096)), dim3(256), 0,
+                           ctx->stream, pooled, m->fcw, m->fcb, B, ICL_FEAT_DIM, ICL_FC_OUT, d_out);
+    }
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}
+
+static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out)
+{
+    if (!ctx->model) return icl_fail(ctx, ICL_ERR_NOMODEL, "no model loaded (call icl_model_load_* first)");
+    if (head != ICL_HEAD_POOLED && head != ICL_HEAD_DENSE0) return icl_fail(ctx, ICL_ERR_ARG, "head must be 2048 or 1000");
+    if (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) return icl_fail(ctx, ICL_ERR_ARG, "prec must be ICL_PREC_FP32 or ICL_PREC_BF16");
+    if (n == 0) return ICL_OK;
+    const int batch = (int)std::min<int64_t>(ctx->batch, n);
+    ICL_TRY(ensure_ws(ctx, batch, prec));
+    hipEvent_t e0, e1;
+    ICL_HIP(ctx, hipEventCreate(&e0));
+    ICL_HIP(ctx, hipEventCreate(&e1));
+    ICL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int64_t i = 0; i < n; i += batch) {
+        const int B = (int)std::min<int64_t>(batch, n - i);
+        const int rc = prec == ICL_PREC_BF16 ? forward_batch<BF16>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head)
+                                             : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head);
+        if (rc) return rc;
+    }
+    ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ctx->last_embed_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    icl_prof_collect(ctx);
+    return ICL_OK;
+}
+
+extern "C" int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out)
+{
+    if (!ctx || n < 0 || (n && (!d_img || !d_out))) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_u8_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    return embed_dev_locked(ctx, d_img, n, head, prec, d_out);
+}
+
+extern "C" int icl_embed_u8(icl_ctx *ctx, const uint8_t *img, int64_t n, int head, int prec, float *out)
+{
+    if (!ctx || n < 0 || (n && (!img || !out))) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_u8: bad argument");
+    if (head != ICL_HEAD_POOLED && head != ICL_HEAD_DENSE0) return icl_fail(ctx, ICL_ERR_ARG, "head must be 2048 or 1000");
+    if (n == 0) return ICL_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    uint8_t *d_img = nullptr;
+    float *d_out = nullptr;
+    // stream the images through in slabs of at most 4096 so host-side callers never need N*150 KB of HBM at once
+    const int64_t slab = std::min<int64_t>(n, 4096);
+    ICL_HIP(ctx, hipMalloc((void **)&d_img, (size_t)slab * ICL_IMG_BYTES));
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)slab * head * 4);
+    int rc = e == hipSuccess ? ICL_OK : icl_fail(ctx, ICL_ERR_NOMEM, "embed output buffer: %s", hipGetErrorString(e));
+    double total_ms = 0;
+    for (int64_t i = 0; rc == ICL_OK && i < n; i += slab) {
+        const int64_t cnt = std::min(slab, n - i);
+        e = hipMemcpyAsync(d_img, img + i * ICL_IMG_BYTES, (size_t)cnt * ICL_IMG_BYTES, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            rc = icl_fail(ctx, ICL_ERR_HIP, "image upload: %s", hipGetErrorString(e));
+            break;
+        }
+        rc = embed_dev_locked(ctx, d_img, cnt, head, prec, d_out);
+        total_ms += ctx->last_embed_ms;
+        if (rc == ICL_OK) {
+            e = hipMemcpyAsync(out + i * head, d_out, (size_t)cnt * head * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "embedding copy-back: %s", hipGetErrorString(e));
+        }
+    }
+    ctx->last_embed_ms = total_ms;
+    if (d_img) (void)hipFree(d_img);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host-side image ingest (embeddings.go:46-116): binary PPM decode + OpenCV-compatible 8-bit bilinear resize
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int icl_preprocess_u8(const uint8_t *hwc, float *nchw)
+{
+    if (!hwc || !nchw) return ICL_ERR_ARG;
+    const float sc = (float)(1.0 / 255.0);
+    for (int y = 0; y < ICL_IMG_H; ++y)
+        for (int x = 0; x < ICL_IMG_W; ++x)
+            for (int c = 0; c < 3; ++c) nchw[((size_t)c * ICL_IMG_H + y) * ICL_IMG_W + x] = (float)hwc[((size_t)y * ICL_IMG_W + x) * 3 + c] * sc;
+    return ICL_OK;
+}
+
+// cv::resize(INTER_LINEAR) for 8-bit images: half-pixel centres, 11-bit fixed-point coefficients, the two-pass
+// rounding of OpenCV's HResizeLinear/VResizeLinear<uchar> (embeddings.go:69 resizes every image to 224x224).
+static void resize_bilinear_u8(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+    const int cn = 3;
+    std::vector<int> xofs((size_t)dw), yofs((size_t)dh);
+    std::vector<short> xa((size_t)dw * 2), ya((size_t)dh * 2);
+    auto coeffs = [](int dn, int sn, std::vector<int> &ofs, std::vector<short> &al) {
+        const double scale = (double)sn / dn;
+        for (int d = 0; d < dn; ++d) {
+            float f = (float)((d + 0.5) * scale - 0.5);
+            int s = (int)std::floor(f);
+            f -= s;
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= sn - 1) { f = 0; s = sn - 1; }
+            ofs[(size_t)d] = s;
+            al[(size_t)d * 2] = (short)std::lrint((1.f - f) * 2048.f);
+            al[(size_t)d * 2 + 1] = (short)std::lrint(f * 2048.f);
+        }
+    };
+    coeffs(dw, sw, xofs, xa);
+    coeffs(dh, sh, yofs, ya);
+    std::vector<int> row0((size_t)dw * cn), row1((size_t)dw * cn);
+    auto hrow = [&](int sy, std::vector<int> &out) {
+        const uint8_t *S = src + (size_t)sy * sw * cn;
+        for (int dx = 0; dx < dw; ++dx) {
+            const int sx = xofs[(size_t)dx], sx1 = std::min(sx + 1, sw - 1);
+            for (int c = 0; c < cn; ++c) out[(size_t)dx * cn + c] = S[sx * cn + c] * xa[(size_t)dx * 2] + S[sx1 * cn + c] * xa[(size_t)dx * 2 + 1];
+        }
+    };
+    for (int dy = 0; dy < dh; ++dy) {
+        const int sy = yofs[(size_t)dy], sy1 = std::min(sy + 1, sh - 1);
+        hrow(sy, row0);
+        hrow(sy1, row1);
+        const int b0 = ya[(size_t)dy * 2], b1 = ya[(size_t)dy * 2 + 1];
+        for (int i = 0; i < dw * cn; ++i)
+            dst[(size_t)dy * dw * cn + i] = (uint8_t)((((b0 * (row0[(size_t)i] >> 4)) >> 16) + ((b1 * (row1[(size_t)i] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+static int read_ppm(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path); // embeddings.go:52
+    auto token = [&](int &v) -> bool {
+        int c;
+        do {
+            c = fgetc(f);
+            if (c == '#')
+                while (c != '\n' && c != EOF) c = fgetc(f);
+        } while (c == ' ' || c == '\n' || c == '\r' || c == '\t');
+        if (c < '0' || c > '9') return false;
+        v = 0;
+        while (c >= '0' && c <= '9') {
+            v = v * 10 + (c - '0');
+            c = fgetc(f);
+        }
+        return true;
+    };
+    int maxv = 0;
+    bool ok = fgetc(f) == 'P' && fgetc(f) == '6' && token(w) && token(h) && token(maxv) && maxv == 255 && w > 0 && h > 0 && w <= 16384 && h <= 16384;
+    if (ok) {
+        rgb.resize((size_t)w * h * 3);
+        ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    }
+    fclose(f);
+    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only binary PPM (P6, maxval 255) is decoded by this build (JPEG: SURVEY.md 8f-2)", path);
+    return ICL_OK;
+}
+
+extern "C" int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out)
+{
+    if (!ctx || !path || !out) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_file: bad argument");
+    std::vector<uint8_t> rgb, img((size_t)ICL_IMG_BYTES);
+    int w = 0, h = 0;
+    ICL_TRY(read_ppm(ctx, path, rgb, w, h));
+    resize_bilinear_u8(rgb.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
+    return icl_embed_u8(ctx, img.data(), 1, head, ICL_PREC_FP32, out);
+}

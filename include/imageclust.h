@@ -81,6 +81,13 @@ int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
 /* PreprocessImage alone: the 1x3x224x224 fp32 NCHW blob of embeddings.go:96-108 (host). */
 int icl_preprocess_u8(const uint8_t *hwc_rgb, float *nchw);
 int icl_set_batch(icl_ctx *ctx, int batch); /* embed batch size, 1..1024 */
+/* One fused convolution layer of the engine (the unit every ResNet50 conv is lowered to), host buffers:
+ * y = relu?( conv(x, w) * scale[c] + shift[c] (+ residual) ).  x: [B][H][H][Cin] NHWC fp32, w: [Cout][Cin][k][k]
+ * (OIHW, as in the ONNX initializer), residual / y: [B][Ho][Ho][Cout] NHWC fp32.  Needs Cin % 32 == 0 and
+ * Cout % 64 == 0.  Operands are rounded to bf16 when prec == ICL_PREC_BF16. */
+int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int Cin, const float *w, int Cout, int k,
+                     int stride, int pad, const float *scale, const float *shift, const float *residual, int relu,
+                     float *y);
 
 /* ---- Ward clustering: replaces internal/clustering/clustering.go --------------------------------------- */
 /* CalculateOptimalClusters (clustering.go:168-186). ICL_ERR_CONSTRAINT on the reference's error branches. */

@@ -1,0 +1,165 @@
+"""GPU parity tests of the hand-written ResNet50 forward (imageclust_amd/csrc/resnet.hip) against the CPU oracle,
+through the C-ABI.  Tolerances (BASELINE.json north_star): fp32 path <= 1e-4 (relative to the output scale, i.e.
+|err| <= 1e-4*max(1,max|ref|)); the bf16 throughput path is reported against its own stated bound of 3e-2."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from imageclust_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    c = L.Context(0)
+    c.load_synthetic(1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def blob(L):
+    return L.synthetic_blob(1)
+
+
+def bf16_round(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.view(np.float32)
+
+
+def ref_conv(x_nhwc, w, scale, shift, stride, pad, res, relu):
+    B, H, _, Cin = x_nhwc.shape
+    Cout, _, k, _ = w.shape
+    Ho = (H + 2 * pad - k) // stride + 1
+    out = np.empty((B, Ho, Ho, Cout), np.float32)
+    for b in range(B):
+        x = np.ascontiguousarray(x_nhwc[b].transpose(2, 0, 1))
+        y = np.zeros((Cout, Ho, Ho), np.float32)
+        O.lib().icl_ref_conv2d(x, Cin, H, H, np.ascontiguousarray(w), None, Cout, k, stride, pad, y, Ho, Ho)
+        y = y * scale[:, None, None] + shift[:, None, None]
+        y = y.transpose(1, 2, 0)
+        if res is not None:
+            y = y + res[b]
+        out[b] = np.maximum(y, 0) if relu else y
+    return out
+
+
+# (cin, cout, k, stride, pad, H): every distinct conv shape of ResNet50-v1 except the lowered stem
+SHAPES = [(64, 64, 1, 1, 0, 56), (64, 64, 3, 1, 1, 56), (64, 256, 1, 1, 0, 56), (256, 64, 1, 1, 0, 56),
+          (256, 128, 1, 2, 0, 56), (128, 128, 3, 1, 1, 28), (128, 512, 1, 1, 0, 28), (256, 512, 1, 2, 0, 56),
+          (512, 128, 1, 1, 0, 28), (512, 256, 1, 2, 0, 28), (256, 256, 3, 1, 1, 14), (256, 1024, 1, 1, 0, 14),
+          (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14), (1024, 512, 1, 2, 0, 14), (512, 512, 3, 1, 1, 7),
+          (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14), (2048, 512, 1, 1, 0, 7), (160, 64, 1, 1, 0, 112)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "c%d-%d_k%d_s%d_h%d" % (s[0], s[1], s[2], s[3], s[5]))
+def test_conv_layer_fp32_and_bf16(ctx, L, shape):
+    cin, cout, k, stride, pad, H = shape
+    rng = np.random.default_rng(cin * 7 + cout + k)
+    B = 2 if H <= 28 else 1
+    x = rng.standard_normal((B, H, H, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = rng.standard_normal((B, Ho, Ho, cout)).astype(np.float32) if k == 1 and cout >= 256 else None
+    relu = (cout % 128 == 0)
+    y = ctx.conv2d_fused(x, w, scale, shift, stride, pad, res, relu, L.PREC_FP32)
+    r = ref_conv(x, w, scale, shift, stride, pad, res, relu)
+    assert np.abs(y - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
+    yb = ctx.conv2d_fused(x, w, scale, shift, stride, pad, res, relu, L.PREC_BF16)
+    rb = ref_conv(bf16_round(x), bf16_round(w), scale, shift, stride, pad, None if res is None else bf16_round(res), relu)
+    assert np.abs(yb - rb).max() <= 1.2e-2 * max(1.0, np.abs(rb).max())  # bf16 output rounding: 2^-8 relative
+
+
+def test_conv_partial_tiles_and_small_batch(ctx, L):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 7, 7, 64)).astype(np.float32)  # M = 147: one full + one ragged 128-row tile
+    w = rng.standard_normal((64, 64, 3, 3)).astype(np.float32) * 0.05
+    sc, sh = np.ones(64, np.float32), np.zeros(64, np.float32)
+    y = ctx.conv2d_fused(x, w, sc, sh, 1, 1, None, False, L.PREC_FP32)
+    r = ref_conv(x, w, sc, sh, 1, 1, None, False)
+    assert np.abs(y - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
+
+
+def test_full_forward_fp32_matches_oracle(ctx, L, blob):
+    imgs = np.concatenate([L.synth_images(20250217, 0, 2, L.SYNTH_NOISE), L.synth_images(20250217, 7, 1, L.SYNTH_STRUCTURED)])
+    ctx.set_batch(2)  # 3 images at batch 2: exercises the ragged last batch
+    pooled = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32)
+    dense = ctx.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_FP32)
+    ctx.set_batch(256)
+    for i in range(3):
+        rp, rd = O.resnet50_forward(blob, imgs[i])
+        assert np.abs(pooled[i] - rp).max() <= 1e-4 * max(1.0, np.abs(rp).max()), i
+        assert np.abs(dense[i] - rd).max() <= 1e-4 * max(1.0, np.abs(rd).max()), i
+    assert pooled.shape == (3, 2048) and dense.shape == (3, 1000)
+
+
+def test_full_forward_bf16_error_bound(ctx, L, blob):
+    imgs = L.synth_images(20250217, 40, 4, L.SYNTH_STRUCTURED)
+    e = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_BF16)
+    f = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32)
+    rel = np.linalg.norm(e - f, axis=1) / np.linalg.norm(f, axis=1)
+    print("bf16 vs fp32 relative L2 error per image:", rel)
+    assert rel.max() < 3e-2
+    # batch invariance: the same image embeds identically alone and inside a batch
+    one = ctx.embed_u8(imgs[2:3], L.HEAD_POOLED, L.PREC_BF16)
+    assert np.array_equal(one[0], e[2])
+
+
+def test_golden_fixture(ctx, L):
+    g = np.load(os.path.join(GOLD, "resnet50_synth_seed1.npz"))
+    imgs = L.synth_images(int(g["img_seed"]), 0, 4, L.SYNTH_STRUCTURED)
+    pooled = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32)
+    dense = ctx.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_FP32)
+    assert np.abs(pooled - g["pooled"]).max() <= 1e-4 * max(1.0, np.abs(g["pooled"]).max())
+    assert np.abs(dense - g["dense"]).max() <= 1e-4 * max(1.0, np.abs(g["dense"]).max())
+
+
+def test_embed_edge_cases(ctx, L):
+    assert ctx.embed_u8(np.zeros((0, 224, 224, 3), np.uint8)).shape == (0, 2048)
+    with pytest.raises(L.ICLError):
+        ctx.embed_u8(np.zeros((1, 224, 224, 3), np.uint8), head=7)
+    c2 = L.Context(0)
+    with pytest.raises(L.ICLError) as ei:
+        c2.embed_u8(np.zeros((1, 224, 224, 3), np.uint8))
+    assert ei.value.code == L.ICL_ERR_NOMODEL
+    c2.close()
+
+
+def test_reference_style_api(ctx, L, tmp_path):
+    from imageclust_amd import embeddings as EM
+
+    net, err = EM.LoadPretrainedModelONNX(str(tmp_path / "missing.onnx"))
+    assert err is not None and "failed to load ResNet50 ONNX model from" in err and net.Empty()
+    net, err = EM.LoadPretrainedModelONNX("synthetic:1")
+    assert err is None and not net.Empty()
+    app = EM.AppContext(Net=net)
+    img = L.synth_images(20250217, 5, 1, L.SYNTH_STRUCTURED)[0]
+    p = tmp_path / "img.ppm"
+    p.write_bytes(b"P6\n224 224\n255\n" + img.tobytes())
+    emb, err = EM.GetImageEmbedding(app, str(p))
+    assert err is None and emb.shape == (1000,)
+    assert np.array_equal(emb, ctx.embed_u8(img[None], L.HEAD_DENSE0, L.PREC_FP32)[0])  # 224x224: resize is identity
+    mat, err = EM.PreprocessImage(str(p))
+    assert err is None and mat.Size() == [1, 3, 224, 224]
+    assert np.array_equal(mat.Blob()[0], (img.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1))
+    emb2, err = EM.GenerateEmbedding(app, str(tmp_path / "nope.ppm"))
+    assert emb2 is None and "failed to read image" in err
+    big = np.random.default_rng(0).integers(0, 256, (260, 300, 3), dtype=np.uint8)
+    q = tmp_path / "big.ppm"
+    q.write_bytes(b"P6\n300 260\n255\n" + big.tobytes())
+    emb3, err = EM.GetImageEmbedding(app, str(q))
+    assert err is None and np.isfinite(emb3).all()
+    net.Close()

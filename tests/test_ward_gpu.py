@@ -197,3 +197,18 @@ def test_cluster_property_sizes_at_scale(ctx):
     # idempotence: same input -> same result
     cid2, rank2, _ = ctx.cluster(E, 5, 50)
     assert np.array_equal(cid, cid2) and np.array_equal(rank, rank2)
+
+
+def test_golden_fixtures(ctx):
+    import os
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "ward_mog_n64_d32.npz"))
+    cid, rank, nc = ctx.cluster(g["E"], int(g["min_size"]), int(g["max_size"]))
+    assert np.array_equal(cid, g["cluster_id"]) and np.array_equal(rank, g["member_rank"]) and nc == int(g["n_clusters"])
+    assert np.array_equal(ctx.last_merges(), g["merges"])
+    t = np.load(os.path.join(gold, "ward_ties_n48_d4.npz"))
+    for mn, mx in [(1, 48), (2, 6), (1, 2), (3, 4)]:
+        cid, rank, _ = ctx.cluster(t["E"], mn, mx)
+        assert np.array_equal(cid, t["cid_%d_%d" % (mn, mx)]) and np.array_equal(rank, t["rank_%d_%d" % (mn, mx)])
+        assert np.array_equal(ctx.last_merges(), t["merges_%d_%d" % (mn, mx)])
