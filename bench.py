@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec (embed + Ward) of the MI355X engine, BASELINE.json's metric.
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+    u8 images (per rank) -> ResNet50-v1 bf16 embed (batch 256) -> [N>1: RCCL all-gather of E over xGMI]
+    -> size-constrained Ward (min=5, max=50, exact update: cluster ids bit-identical to the reference)
+    -> cluster_id[N] on the host.
+N=1 runs BASELINE.json configs[1] (10 000 synthetic 224x224x3 images, 1 GPU).  N>1 is weak scaling: every rank
+embeds the same number of images; rank 0 clusters the gathered E (configs[2]'s shape: "Ward on GPU0").
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.  PyTorch is used for device buffers, barriers and the all-gather only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# roofline denominators (/opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters")
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_IMAGE = 2 * 3857973248  # 53 conv + 1 fc, MACs x 2
+
+
+def cpu_baseline(n_embed=16, n_ward=1500, d=2048):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port"), timed on this box's host cores."""
+    from oracle import oracle as O
+    from imageclust_amd import _lib
+
+    cores = os.cpu_count() or 1
+    blob = _lib.synthetic_blob(1)
+    imgs = _lib.synth_images(20250217, 0, n_embed, _lib.SYNTH_STRUCTURED)
+    O.resnet50_forward(blob, imgs[0])  # warm
+    t0 = time.perf_counter()
+    for im in imgs:
+        O.resnet50_forward(blob, im)  # batch 1, serial calls, OpenMP inside: as embeddings.go:133-141
+    t_embed = time.perf_counter() - t0
+    rng = np.random.default_rng(20250217)
+    cen = rng.standard_normal((n_ward // 20, d)).astype(np.float32)
+    E = (cen[rng.integers(0, len(cen), n_ward)] + 0.1 * rng.standard_normal((n_ward, d))).astype(np.float32)
+    t0 = time.perf_counter()
+    O.cluster(E, 5, 50)
+    t_ward = time.perf_counter() - t0
+    embed_rate = n_embed / t_embed
+    value = n_ward / (n_ward / embed_rate + t_ward)
+    return {"value": round(value, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ CPU restatement: embed %d images (batch 1, OpenMP %d threads, %.2f img/s) + Ward N=%d D=%d "
+                      "min=5 max=50 (1 thread, %.2f s); value = %d/(%d/embed_rate + t_ward)"
+                      % (n_embed, cores, embed_rate, n_ward, d, t_ward, n_ward, n_ward),
+            "embed_images_per_sec": round(embed_rate, 3), "ward_seconds": round(t_ward, 3), "ward_n": n_ward}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--min-size", type=int, default=5)
+    ap.add_argument("--max-size", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--embed-only", action="store_true", help="configs[3]: embed throughput without clustering")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    from imageclust_amd import _lib
+
+    ctx = _lib.Context(local_rank)
+    ctx.load_synthetic(1)
+    ctx.set_batch(args.batch)
+    n_local = args.images_per_gpu
+    n_total = n_local * world
+    D = _lib.HEAD_POOLED
+
+    # synthetic inputs, generated on-device and resident in HBM before any timed region
+    imgs = torch.empty(n_local * _lib.IMG_BYTES, dtype=torch.uint8, device=dev)
+    ctx.synth_images_dev(20250217, rank * n_local, n_local, _lib.SYNTH_STRUCTURED, imgs.data_ptr())
+    ctx.sync()
+    E_local = torch.empty((n_local, D), dtype=torch.float32, device=dev)
+    E_full = torch.empty((n_total, D), dtype=torch.float32, device=dev) if world > 1 else E_local
+    result = {}
+
+    def step():
+        ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), D, _lib.PREC_BF16)  # returns with the stream idle
+        st = ctx.last_stage_ms()
+        result["embed_ms"] = st["embed_ms"]
+        if world > 1:
+            t0 = time.perf_counter()
+            dist.all_gather_into_tensor(E_full, E_local)
+            torch.cuda.synchronize()
+            result["allgather_ms"] = (time.perf_counter() - t0) * 1e3
+        if args.embed_only:
+            return
+        if rank == 0:
+            cid, mrank, nc = ctx.cluster_dev(E_full.data_ptr(), n_total, D, args.min_size, args.max_size)
+            st = ctx.last_stage_ms()
+            result.update(dist_ms=st["dist_ms"], merge_ms=st["merge_ms"], n_clusters=nc, merges=len(ctx.last_merges()),
+                          dropped=int((cid < 0).sum()))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    conv_mask = (1 << _lib.K_CONV) | (1 << _lib.K_CONV64)
+    ctx.prof_reset()
+    ctx.prof_enable(conv_mask)  # HIP events around every conv launch, on the engine's own stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
+        value = n_total * args.steps / elapsed
+        c128, c64 = ctx.prof_query(_lib.K_CONV), ctx.prof_query(_lib.K_CONV64)
+        # dominant kernel: conv_igemm_kernel<BF16,128> (all Cout>=128 convolutions)
+        avg_us = c128["ms"] * 1e3 / max(c128["launches"], 1)
+        achieved = c128["flops"] / max(c128["ms"], 1e-9) / 1e9  # TFLOP/s
+        name, ncu, hbm = ctx.device_info()
+        out = {
+            "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic 224x224x3 images per GPU (structured, seed 20250217), ResNet50-v1 bf16 "
+                                   "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d exact update on GPU0 -> cluster ids on host"
+                                   % (n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
+                       "n_images_total": n_total, "embed_dim": D, "weights": "synthetic seed 1", "device": name},
+            "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
+            "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
+                         "algorithmic_flops_per_launch": round(c128["flops"] / max(c128["launches"], 1), 0),
+                         "all_conv_achieved": round((c128["flops"] + c64["flops"]) / max(c128["ms"] + c64["ms"], 1e-9) / 1e9, 2),
+                         "embed_frac_of_bf16_peak": round(n_local * FLOP_PER_IMAGE / max(result.get("embed_ms", 0), 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,8 +17,9 @@ HEAD_POOLED, HEAD_DENSE0 = 2048, 1000
 PREC_FP32, PREC_BF16 = 0, 1
 UPDATE_EXACT, UPDATE_LW = 0, 1
 SYNTH_NOISE, SYNTH_STRUCTURED = 0, 1
-K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER = range(6)
-K_NAMES = ["conv_igemm", "ward_dist_exact", "dist_mfma", "row_argmin", "ward_update_exact", "embed_other"]
+K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER, K_CONV64 = range(7)
+K_NAMES = ["conv_igemm_kernel<*,128>", "ward_dist_exact_kernel", "dist_mfma_kernel", "row_argmin_*_kernel",
+           "ward_update_exact_kernel", "embed_other", "conv_igemm_kernel<*,64>"]
 IMG_BYTES = 224 * 224 * 3
 
 # every symbol include/imageclust.h declares: (name, restype, argtypes)
@@ -163,8 +164,11 @@ class Context:
         return buf.value.decode(), ncu.value, hbm.value
 
     # -- profiling ------------------------------------------------------------------------------------
-    def prof_enable(self, on=True):
-        check(self.h, self.L.icl_prof_enable(self.h, 1 if on else 0))
+    def prof_enable(self, mask=-1):
+        """mask: bit k brackets kernel class k with HIP events (True/-1 = all, False/0 = off)."""
+        if mask is True:
+            mask = -1
+        check(self.h, self.L.icl_prof_enable(self.h, int(mask)))
 
     def prof_reset(self):
         check(self.h, self.L.icl_prof_reset(self.h))

@@ -35,7 +35,7 @@ struct icl_ctx {
     hipDeviceProp_t prop;
     int batch = 256;
     // profiling
-    bool prof_on = false;
+    int prof_mask = 0;
     icl_prof_slot prof[ICL_K_NCLASS];
     std::vector<icl_pending_event> pending;
     std::vector<hipEvent_t> event_pool;

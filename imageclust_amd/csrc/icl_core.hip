@@ -161,7 +161,7 @@ static hipEvent_t take_event(icl_ctx *c)
 
 icl_prof_scope::icl_prof_scope(icl_ctx *ctx, int kclass, double flops, double bytes) : c(ctx), k(kclass)
 {
-    if (!c->prof_on) return;
+    if (!((c->prof_mask >> k) & 1)) return;
     c->prof[k].flops += flops;
     c->prof[k].bytes += bytes;
     c->prof[k].launches += 1;
@@ -188,11 +188,11 @@ void icl_prof_collect(icl_ctx *ctx)
     ctx->pending.clear();
 }
 
-extern "C" int icl_prof_enable(icl_ctx *ctx, int on)
+extern "C" int icl_prof_enable(icl_ctx *ctx, int class_mask)
 {
     if (!ctx) return ICL_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->prof_on = on != 0;
+    ctx->prof_mask = class_mask;
     return ICL_OK;
 }
 

@@ -592,7 +592,7 @@ template <typename T>
 static int launch_conv_t(icl_ctx *ctx, const conv_args &a)
 {
     const unsigned gx = (unsigned)icl_ceil_div(a.M, CV_BM);
-    icl_prof_scope ps(ctx, ICL_K_CONV, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    icl_prof_scope ps(ctx, a.Cout % 128 == 0 ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
     if (a.Cout % 128 == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(gx, a.Cout / 128), dim3(256), 0, ctx->stream, a);
     else

@@ -126,15 +126,17 @@ int icl_synth_images_dev(icl_ctx *ctx, uint64_t seed, int64_t first, int64_t n, 
 
 /* ---- in-library HIP-event timing of the kernel classes (bench.py roofline) --------------------------------- */
 enum {
-    ICL_K_CONV = 0,       /* all implicit-GEMM conv launches */
+    ICL_K_CONV = 0,       /* implicit-GEMM conv launches, 128x128 tile (conv_igemm_kernel<*,128>) */
     ICL_K_DIST_EXACT = 1, /* exact Ward distance tile (K6x) */
     ICL_K_DIST_MFMA = 2,  /* MFMA distance tile (K6) */
     ICL_K_ROWMIN = 3,     /* masked row argmin scans (K7) */
     ICL_K_UPDATE = 4,     /* per-merge exact row update (K8) */
     ICL_K_EMBED_OTHER = 5,/* im2col, pooling, fc */
-    ICL_K_NCLASS = 6
+    ICL_K_CONV64 = 6,     /* implicit-GEMM conv launches, 128x64 tile (Cout == 64 layers) */
+    ICL_K_NCLASS = 7
 };
-int icl_prof_enable(icl_ctx *ctx, int on);
+/* class_mask: bit k enables HIP-event bracketing of kernel class k (0 = off, -1 = all). */
+int icl_prof_enable(icl_ctx *ctx, int class_mask);
 int icl_prof_reset(icl_ctx *ctx);
 /* Accumulated since reset: device milliseconds, launches, algorithmic flops, algorithmic bytes. */
 int icl_prof_query(icl_ctx *ctx, int kclass, double *ms, int64_t *launches, double *flops, double *bytes);
