@@ -36,7 +36,9 @@ def cpu_baseline(n_embed=16, n_ward=1500, d=2048):
     from oracle import oracle as O
     from imageclust_amd import _lib
 
-    cores = os.cpu_count() or 1
+    # the oracle's OpenMP team: the CPUs this process may run on, capped at 16 (a 1-GPU box's CPU share)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     blob = _lib.synthetic_blob(1)
     imgs = _lib.synth_images(20250217, 0, n_embed, _lib.SYNTH_STRUCTURED)
     O.resnet50_forward(blob, imgs[0])  # warm
