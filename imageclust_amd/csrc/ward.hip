@@ -27,7 +27,11 @@ struct ward_state {
     int32_t rescan_n;  // rows queued for a (min,argmin) rescan
     int32_t cur_a, cur_b, cur_c; // creation ids: merged pair (a = higher position) and the new cluster
     int32_t cur_valid; // the current step performed a merge
+    int32_t target;    // merges to perform: N - k (clustering.go:220); further steps are no-ops
+    int32_t nlive;     // live clusters occupy the dense slot range [0, nlive)
+    int32_t mv_from, mv_to; // slot compaction of the current step: cluster in slot mv_from moves to mv_to (-1: none)
     int32_t pad;
+    unsigned long long ckey; // (value bits << 32 | column id) minimum of the new cluster's row, built with atomicMin
 };
 
 struct icl_ward_ws {
@@ -35,6 +39,7 @@ struct icl_ward_ws {
     int32_t capD = 0;
     int64_t S = 0, M = 0;
     float *CT = nullptr;       // [D][S] centroids, transposed: slot-contiguous
+    float *Crow = nullptr;     // [S][D] the same centroids, cluster-contiguous (coalesced merge of two centroids)
     float *cnew = nullptr;     // [D] centroid of the cluster created by the current step
     int32_t *slot_id = nullptr;// [S] creation id held by a slot, -1 if free
     int32_t *id_slot = nullptr;// [M]
@@ -53,14 +58,18 @@ struct icl_ward_ws {
     int64_t fc_cap = 0;
     int64_t *fc_out = nullptr;
     std::vector<int64_t> h_rowoff;
+    // hipGraph of GRAPH_STEPS merge steps (all step-varying state lives in device memory, so one capture replays)
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_max_size = -1;
 };
 
 void icl_ward_free(icl_ctx *ctx)
 {
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
-    void *ptrs[] = {w->CT, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+    void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
                     w->merges, w->rescan, w->st, w->fc_min, w->fc_nn, w->fc_out};
+    if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete w;
@@ -266,18 +275,25 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
     bi = -1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
     const int64_t nvec = aligned ? (len >> 2) : 0;
-    for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x) {
-        const float4 v = reinterpret_cast<const float4 *>(row)[q];
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        int4 m = make_int4(1, 1, 1, 1);
-        if (asz) m = reinterpret_cast<const int4 *>(asz)[q];
-        const int mm[4] = {m.x, m.y, m.z, m.w};
+    // 4 columns per load, 2 loads (+ their masks) in flight per lane; a lane visits its columns in ascending order
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 2 * (int64_t)blockDim.x) {
+        const int64_t q1 = q0 + blockDim.x;
+        const bool has1 = q1 < nvec;
+        const float4 va = reinterpret_cast<const float4 *>(row)[q0];
+        const float4 vb = has1 ? reinterpret_cast<const float4 *>(row)[q1] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+        int4 ma = make_int4(1, 1, 1, 1), mb = make_int4(1, 1, 1, 1);
+        if (asz) {
+            ma = reinterpret_cast<const int4 *>(asz)[q0];
+            if (has1) mb = reinterpret_cast<const int4 *>(asz)[q1];
+        }
+        const float vv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const int mm[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const bool ok = asz ? (mm[e] > 0 && mm[e] + my_size <= max_size) : true;
             if (ok && vv[e] < bv) {
                 bv = vv[e];
-                bi = (int)(q * 4 + e);
+                bi = (int)((e < 4 ? q0 : q1) * 4 + (e & 3));
             }
         }
     }
@@ -294,15 +310,31 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
 }
 
 // rows: explicit list (list != nullptr, *count entries) or 0..nrows-1.  Packed triangle addressing.
-__global__ __launch_bounds__(256) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
+__global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                                             const int32_t *__restrict__ asz, int max_size,
                                                             const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                            int64_t nrows, const ward_state *__restrict__ st,
-                                                            float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+                                                            int64_t nrows, ward_state *__restrict__ st,
+                                                            float *__restrict__ rowmin, int32_t *__restrict__ rownn,
+                                                            int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot)
 {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    if (st && st->done) return;
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    if (st && (st->done || !st->cur_valid)) return;
+    if (st && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the update kernel reduced the new cluster's row with atomicMin on (value bits, column): publish it
+        const unsigned long long key = st->ckey;
+        const int c = st->cur_c;
+        rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
+        rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
+        // slot compaction: the update kernel copied the centroid in slot mv_from to the freed slot mv_to
+        if (st->mv_to >= 0) {
+            const int y = slot_id[st->mv_from];
+            slot_id[st->mv_to] = y;
+            id_slot[y] = st->mv_to;
+            slot_id[st->mv_from] = -1;
+        }
+        st->nlive = st->nlive - 1;
+    }
     const int64_t total = list ? (int64_t)(*count) : nrows;
     for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
         const int64_t r = list ? list[idx] : idx;
@@ -324,11 +356,11 @@ __global__ __launch_bounds__(256) void row_argmin_tri_kernel(const float *__rest
 }
 
 // Dense n x n matrix (API FindClosestClusters): row r scans columns 0..r-1, no mask.
-__global__ __launch_bounds__(256) void row_argmin_dense_kernel(const float *__restrict__ D, int64_t n, int64_t ld,
+__global__ __launch_bounds__(1024) void row_argmin_dense_kernel(const float *__restrict__ D, int64_t n, int64_t ld,
                                                               float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+    __shared__ float sv[16];
+    __shared__ int si[16];
     for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
         float bv;
         int bi;
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(1024) void select_dense_kernel(const float *__restr
 // Merge loop kernels
 // ------------------------------------------------------------------------------------------------------------
 __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_id, int32_t *id_slot, int32_t *asz,
-                                 float *rowmin, int32_t *rownn, ward_state *st)
+                                 float *rowmin, int32_t *rownn, ward_state *st, int32_t target)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < S) slot_id[i] = i < n ? (int32_t)i : -1;
@@ -383,51 +415,89 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->rescan_n = 0;
         st->cur_a = st->cur_b = st->cur_c = -1;
         st->cur_valid = 0;
+        st->target = target;
+        st->nlive = (int32_t)n;
+        st->mv_from = st->mv_to = -1;
+        st->ckey = ~0ull;
     }
 }
 
-// E [n][d] row-major -> CT [d][S] (slot-contiguous), 32x32 tiles through LDS.
+// Centroid store used by the update kernel: CT4[g][slot][4] = centroid(slot)[4g .. 4g+3]  (k-groups of 4 are
+// contiguous per slot, slots contiguous per group): one dwordx4 per lane streams 4 consecutive k of the lane's slot
+// and a wave's load is 1 KiB contiguous.  Groups >= ceil(d/4) are zero.
+__device__ __forceinline__ int64_t ct4_off(int64_t g, int64_t S, int64_t slot) { return (g * S + slot) * 4; }
+
+// E [n][d] row-major -> CT4, 32 slots x 32 groups per workgroup through LDS.
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ E, int64_t n, int d, int64_t S,
-                                                       float *__restrict__ CT)
+                                                       float *__restrict__ CT4)
 {
-    __shared__ float tile[32][33];
+    __shared__ float4 tile[32][33];
     const int64_t r0 = (int64_t)blockIdx.x * 32;
-    const int k0 = blockIdx.y * 32;
+    const int g0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 8 rows per pass
     for (int rr = ty; rr < 32; rr += 8) {
         const int64_t r = r0 + rr;
-        const int k = k0 + tx;
-        tile[rr][tx] = (r < n && k < d) ? E[r * d + k] : 0.0f;
+        const int k = 4 * (g0 + tx);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            if (k + 3 < d && (d & 3) == 0) {
+                v = *reinterpret_cast<const float4 *>(E + r * d + k);
+            } else {
+                if (k + 0 < d) v.x = E[r * d + k + 0];
+                if (k + 1 < d) v.y = E[r * d + k + 1];
+                if (k + 2 < d) v.z = E[r * d + k + 2];
+                if (k + 3 < d) v.w = E[r * d + k + 3];
+            }
+        }
+        tile[rr][tx] = v;
     }
     __syncthreads();
-    for (int kk = ty; kk < 32; kk += 8) {
-        const int k = k0 + kk;
+    const int dq = (d + 3) >> 2;
+    for (int gg = ty; gg < 32; gg += 8) {
+        const int g = g0 + gg;
         const int64_t r = r0 + tx;
-        if (k < d && r < S) CT[(int64_t)k * S + r] = tile[tx][kk];
+        if (g < dq && r < S) *reinterpret_cast<float4 *>(CT4 + ct4_off(g, S, r)) = tile[tx][gg];
     }
 }
 
 // Step 1/3: pick the globally closest admissible pair and create the merged cluster.
 __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT,
-                                                          float *__restrict__ cnew, int32_t *__restrict__ slot_id,
-                                                          int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
-                                                          float *__restrict__ rowmin, const int32_t *__restrict__ rownn,
-                                                          int32_t *__restrict__ merges, int32_t *__restrict__ rescan,
+                                                          float *__restrict__ Crow, float *__restrict__ cnew,
+                                                          int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot,
+                                                          int32_t *__restrict__ asz, float *__restrict__ rowmin,
+                                                          const int32_t *__restrict__ rownn, int32_t *__restrict__ merges,
                                                           ward_state *__restrict__ st)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
-    __shared__ int sh[4];
+    __shared__ int sh[6];
     if (st->done) return;
     const int t = st->t;
-    const int64_t nrows = n + t;
+    if (t >= st->target) { // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
+        if (threadIdx.x == 0) st->cur_valid = 0;
+        return;
+    }
+    // lexicographic (value, row) minimum over the row caches; rows are read 4 at a time, 4 loads in flight per lane
+    const int64_t nvec = (n + t + 3) >> 2; // rowmin is padded with MaxFloat32 up to a multiple of 4
     float bv = ICL_MAXF;
     int bi = -1;
-    for (int64_t r = threadIdx.x; r < nrows; r += blockDim.x) {
-        const float v = rowmin[r];
-        if (v < bv) { // strict: first row wins among equal minima (clustering.go:125)
-            bv = v;
-            bi = (int)r;
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (e[i] < bv) { // strict: first row wins among equal minima (clustering.go:125)
+                    bv = e[i];
+                    bi = (int)(q * 4 + i);
+                }
         }
     }
     block_argmin(bv, bi, sv, si);
@@ -438,28 +508,32 @@ __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int
             st->rescan_n = 0;
             sh[0] = -1;
         } else {
-            const int a = bi, b = rownn[bi], c = (int)(n + t);
+            const int a = bi, b = rownn[bi];
             sh[0] = a;
             sh[1] = b;
             sh[2] = asz[a];
             sh[3] = asz[b];
+            sh[4] = id_slot[a];
+            sh[5] = id_slot[b];
         }
     }
     __syncthreads();
     const int a = sh[0];
     if (a < 0) return;
-    const int b = sh[1], sa = sh[2], sb = sh[3];
+    const int b = sh[1], sa = sh[2], sb = sh[3], slot_a = sh[4], slot_b = sh[5];
     const int c = (int)(n + t);
-    const int slot_a = id_slot[a], slot_b = id_slot[b];
     // MergeClusters centroid (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb) / float(sa+sb), each op rounded
     const float fa = (float)sa, fb = (float)sb, fs = (float)(sa + sb);
+    float *ra = Crow + (int64_t)slot_a * d;
+    const float *rb = Crow + (int64_t)slot_b * d;
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
-        const float pa = fa * CT[(int64_t)k * S + slot_a];
-        const float pb = fb * CT[(int64_t)k * S + slot_b];
-        const float s = pa + pb;
-        const float cv = s / fs;
+        const float pa = fa * ra[k];
+        const float pb = fb * rb[k];
+        const float sm = pa + pb;
+        const float cv = sm / fs;
         cnew[k] = cv;
-        CT[(int64_t)k * S + slot_a] = cv; // the new cluster inherits a's slot
+        ra[k] = cv;                        // the new cluster inherits a's slot
+        CT[ct4_off(k >> 2, S, slot_a) + (k & 3)] = cv;
     }
     if (threadIdx.x == 0) {
         merges[2 * t] = a;
@@ -473,8 +547,11 @@ __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int
         id_slot[c] = slot_a;
         slot_id[slot_a] = c;
         slot_id[slot_b] = -1;
-        rescan[0] = c;
-        st->rescan_n = 1;
+        const int last = st->nlive - 1; // keep live slots dense: the cluster in the last slot moves into b's slot
+        st->mv_from = slot_b != last ? last : -1;
+        st->mv_to = slot_b != last ? slot_b : -1;
+        st->rescan_n = 0;
+        st->ckey = ~0ull;
         st->cur_a = a;
         st->cur_b = b;
         st->cur_c = c;
@@ -483,54 +560,130 @@ __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int
     }
 }
 
-// Step 2/3 (K8 exact): one lane per slot: WardDistance(x, new) from centroids (clustering.go:84), sequential k,
-// written into the new cluster's row; rows whose cached argmin just died are queued for a rescan.
-#define UPD_U 16
-__global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int64_t S, const float *__restrict__ CT,
-                                                               const float *__restrict__ cnew,
+// Step 2/3 (K8 exact): WardDistance(x, new) from centroids (clustering.go:84) for every live cluster x, sequential
+// k, unfused fp32, written into the new cluster's row.  Algorithmic traffic: 4*n_live*D bytes per merge.
+//
+// The sum over k must be accumulated strictly in order (the reference's loop), i.e. one DEPENDENT fp32 add per k per
+// cluster: ~3 ns each on gfx950, a 6.3 us floor for D = 2048 that no amount of bandwidth removes.  Measured
+// (scratch/chain_bench.hip): a lone wave issues ~1 instruction per 2.3 ns, so a wave that also loads, subtracts and
+// squares spends 9-18 ns per k.  Hence the split: a workgroup of 4 waves owns 64 slots; waves 1-3 (producers) stream
+// the slots' centroids as dwordx4 from the CT4 layout, compute p_k = (x_k - c_k)^2 and hand whole stages of p to wave 0
+// through a double-buffered LDS ring; wave 0 (the chain) only does ds_read_b128 + four dependent v_add_f32 per 4 k.
+// One barrier per stage of 96 k.  Live slots are kept dense ([0, nlive)): the last workgroup copies the centroid of
+// the last live slot into the slot freed by this merge.  The new row's minimum is folded in with one 64-bit
+// atomicMin per workgroup; rows whose cached argmin just died are queued for a rescan.
+#define UPD_P 3                       /* producer waves */
+#define UPD_GP 8                      /* k-groups (float4) per producer per stage */
+#define UPD_SG (UPD_P * UPD_GP)       /* k-groups per stage */
+#define UPD_PAD_G UPD_SG              /* zero groups past the end so the last prefetch needs no guard */
+static inline int64_t upd_groups(int d) { return (((int64_t)d + 3) / 4 + 2 * UPD_SG - 1) / (2 * UPD_SG) * (2 * UPD_SG); }
+
+__global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+                                                               float *__restrict__ Crow, const float *__restrict__ cnew,
                                                                const int32_t *__restrict__ slot_id,
                                                                const int32_t *__restrict__ asz, const int32_t *__restrict__ rownn,
                                                                const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
                                                                int32_t *__restrict__ rescan, ward_state *__restrict__ st,
                                                                int max_size)
 {
+    __shared__ float4 ring[2][UPD_SG][64]; // 48 KiB
     if (st->done || !st->cur_valid) return;
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= S) return;
-    const int x = slot_id[slot];
-    const int a = st->cur_a, b = st->cur_b, c = st->cur_c;
-    if (x < 0 || x == c) return;
-    const int sx = asz[x];
-    if (sx <= 0) return;
-    const int nn = rownn[x];
-    if (nn == a || nn == b) {
-        const int pos = atomicAdd(&st->rescan_n, 1);
-        rescan[pos] = x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == gridDim.x - 1) { // compaction copy (disjoint from every column read below: mv_to is a free slot)
+        const int from = st->mv_from, to = st->mv_to;
+        if (to < 0) return;
+        const int dq = (d + 3) >> 2;
+        for (int g = threadIdx.x; g < dq; g += 256)
+            *reinterpret_cast<float4 *>(CT + ct4_off(g, S, to)) = *reinterpret_cast<const float4 *>(CT + ct4_off(g, S, from));
+        for (int k = threadIdx.x; k < d; k += 256) Crow[(int64_t)to * d + k] = Crow[(int64_t)from * d + k];
+        return;
     }
-    const int sc = asz[c];
-    if (sx + sc > max_size) return; // pair is banned for good (static mask); its value is never read
-    const float *col = CT + slot;
-    float s = 0.0f;
-    int k = 0;
-    for (; k + UPD_U <= d; k += UPD_U) {
-        float v[UPD_U];
-#pragma unroll
-        for (int u = 0; u < UPD_U; ++u) v[u] = col[(int64_t)(k + u) * S];
-#pragma unroll
-        for (int u = 0; u < UPD_U; ++u) {
-            const float df = v[u] - cnew[k + u]; // clusters[i].Centroid - newCluster.Centroid (:139 via :84)
-            const float p = df * df;
-            s = s + p;
+    const int nlive = st->nlive;
+    if ((int64_t)blockIdx.x * 64 >= nlive) return;
+    const int64_t slot = (int64_t)blockIdx.x * 64 + lane; // S is a multiple of 64
+    const int a = st->cur_a, b = st->cur_b, c = st->cur_c;
+    const int x = slot < nlive ? slot_id[slot] : -1;
+    bool live = x >= 0 && x != c;
+    const int sx = live ? asz[x] : 0;
+    live = live && sx > 0;
+    if (live && wave == 0) {
+        const int nn = rownn[x];
+        if (nn == a || nn == b) {
+            const int pos = atomicAdd(&st->rescan_n, 1);
+            rescan[pos] = x;
         }
     }
-    for (; k < d; ++k) {
-        const float df = col[(int64_t)k * S] - cnew[k];
-        const float p = df * df;
-        s = s + p;
+    const int sc = asz[c];
+    const bool act = live && (sx + sc <= max_size); // else: banned for good (static mask); value never read
+    if (!__any(act)) return;                         // same 64 slots in every wave: a workgroup-uniform exit
+    // CT4 and cnew carry dqp + UPD_PAD_G zero-padded groups: padded k contribute (0-0)^2 = +0 exactly and no load
+    // in the pipeline needs a guard.
+    const float4 *col = reinterpret_cast<const float4 *>(CT) + slot;
+    // the new centroid is staged once into LDS: scalar loads would share lgkmcnt with the ring's ds_writes and, being
+    // unordered against them, force lgkmcnt(0) (a full LDS round trip) on every k-group
+    extern __shared__ __attribute__((aligned(16))) float4 cn4[];
+    for (int g = threadIdx.x; g < dqp + UPD_PAD_G; g += 256) cn4[g] = reinterpret_cast<const float4 *>(cnew)[g];
+    __syncthreads();
+    const int pj = wave - 1;
+    float s = 0.0f;
+    float4 va[UPD_GP], vb[UPD_GP];
+    auto load = [&](float4 (&v)[UPD_GP], int stage) {
+        const int g0 = stage * UPD_SG + pj * UPD_GP;
+#pragma unroll
+        for (int u = 0; u < UPD_GP; ++u) v[u] = col[(int64_t)(g0 + u) * S];
+    };
+    auto produce = [&](const float4 (&v)[UPD_GP], int stage, int buf) {
+        const int g0 = stage * UPD_SG + pj * UPD_GP;
+#pragma unroll
+        for (int u = 0; u < UPD_GP; ++u) {
+            const float4 cv = cn4[g0 + u]; // broadcast ds_read_b128
+            const float d0 = v[u].x - cv.x, d1 = v[u].y - cv.y, d2 = v[u].z - cv.z, d3 = v[u].w - cv.w; // :139 via :84
+            ring[buf][pj * UPD_GP + u][lane] = make_float4(d0 * d0, d1 * d1, d2 * d2, d3 * d3);       // :154 products
+        }
+    };
+    auto consume = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < UPD_SG; ++g) {
+            const float4 p = ring[buf][g][lane];
+            s = s + p.x; // :154 the running sum, strictly in k order
+            s = s + p.y;
+            s = s + p.z;
+            s = s + p.w;
+        }
+    };
+    const int nstage = dqp / UPD_SG; // even
+    if (wave > 0) load(va, 0);
+    for (int i = 0; i < nstage; i += 2) {
+        if (wave > 0) {
+            load(vb, i + 1);
+            produce(va, i, 0);
+        }
+        __syncthreads();
+        if (wave == 0) consume(0);
+        if (wave > 0) {
+            load(va, i + 2); // i+2 == nstage on the last pass: zero padding
+            produce(vb, i + 1, 1);
+        }
+        __syncthreads();
+        if (wave == 0) consume(1);
     }
+    if (wave != 0) return;
     const float num = (float)((int64_t)sx * (int64_t)sc);
     const float den = (float)(sx + sc);
-    Dtri[rowoff[c] + x] = (num / den) * s;
+    const float val = (num / den) * s;
+    unsigned long long key = ~0ull;
+    if (act) {
+        Dtri[rowoff[c] + x] = val;
+        // values are >= +0 (a sum of squares scaled by a positive ratio): their bit patterns order like the floats,
+        // so min over (bits<<32 | x) is "smallest value, then smallest column" == the row scan's first strict minimum
+        if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(key, off, 64);
+        key = o < key ? o : key;
+    }
+    if (lane == 0 && key != ~0ull) atomicMin(&st->ckey, key);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -540,16 +693,15 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
 {
     if (!ctx->ward) ctx->ward = new icl_ward_ws();
     icl_ward_ws *w = ctx->ward;
-    if (w->capN >= n && w->capD >= d && w->capN > 0) {
-        // keep geometry consistent with the current problem (S, M depend on n)
-    }
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
-        void *ptrs[] = {w->CT, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+        void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
                         w->merges, w->rescan, w->st};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
-        w->CT = w->cnew = w->rowmin = w->Dtri = nullptr;
+        if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
+        w->graph_exec = nullptr;
+        w->CT = w->Crow = w->cnew = w->rowmin = w->Dtri = nullptr;
         w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = w->rescan = nullptr;
         w->rowoff = nullptr;
         w->st = nullptr;
@@ -573,8 +725,12 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
             return icl_fail(ctx, ICL_ERR_NOMEM, "ward workspace: hipMalloc(%s, %lld x %zu B) failed: %s", #field, \
                             (long long)(count), sizeof(type), hipGetErrorString(e__));                          \
     } while (0)
-        WS_ALLOC(CT, float, dd * w->S);
-        WS_ALLOC(cnew, float, dd);
+        const int64_t ngrp = upd_groups((int)dd) + UPD_PAD_G; // the update kernel streams whole stages and prefetches past the end
+        WS_ALLOC(CT, float, 4 * ngrp * w->S);
+        ICL_HIP(ctx, hipMemsetAsync(w->CT, 0, (size_t)(4 * ngrp * w->S) * sizeof(float), ctx->stream));
+        WS_ALLOC(Crow, float, dd * w->S);
+        WS_ALLOC(cnew, float, 4 * ngrp);
+        ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(4 * ngrp) * sizeof(float), ctx->stream));
         WS_ALLOC(slot_id, int32_t, w->S);
         WS_ALLOC(id_slot, int32_t, w->M);
         WS_ALLOC(asz, int32_t, w->M);
@@ -695,7 +851,7 @@ static int find_closest_locked(icl_ctx *ctx, const float *d_D, int64_t n, int64_
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 32);
-        hipLaunchKernelGGL(row_argmin_dense_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_D, n, ld, w->fc_min, w->fc_nn);
+        hipLaunchKernelGGL(row_argmin_dense_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, d_D, n, ld, w->fc_min, w->fc_nn);
     }
     hipLaunchKernelGGL(select_dense_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->fc_min, w->fc_nn, n, w->fc_out);
     ICL_HIP(ctx, hipGetLastError());
@@ -806,10 +962,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     {
         const int64_t cnt = std::max(w->S, w->M);
         hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, ctx->stream, n, w->S, w->M,
-                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->st);
-        if (d > 0)
-            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)icl_ceil_div(w->S, 32), (unsigned)icl_ceil_div(d, 32)), dim3(256), 0,
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->st, (int32_t)T);
+        if (d > 0) {
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)icl_ceil_div(w->S, 32), (unsigned)icl_ceil_div((d + 3) / 4, 32)), dim3(256), 0,
                                ctx->stream, d_E, n, d, w->S, w->CT);
+            ICL_HIP(ctx, hipMemcpyAsync(w->Crow, d_E, (size_t)n * d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         ICL_HIP(ctx, hipGetLastError());
     }
     // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle
@@ -817,26 +975,52 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
-        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, n, (const ward_state *)nullptr, w->rowmin, w->rownn);
+        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, n, (ward_state *)nullptr, w->rowmin, w->rownn,
+                           w->slot_id, w->id_slot);
         ICL_HIP(ctx, hipGetLastError());
     }
     ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
 
-    const unsigned upd_blocks = (unsigned)icl_ceil_div(w->S, 256);
-    for (int64_t t = 0; t < T; ++t) {
-        hipLaunchKernelGGL(ward_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->cnew, w->slot_id,
-                           w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->rescan, w->st);
-        {
-            icl_prof_scope ps(ctx, ICL_K_UPDATE, 3.0 * (double)(n - t) * d, 4.0 * (double)(n - t) * d);
-            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), 0, ctx->stream, d, w->S, w->CT, w->cnew,
-                               w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
+    // Merge loop: T steps of {select, update, rescan}.  Every step-varying quantity lives in device memory
+    // (ward_state), so the launches are identical and steps past the target / past "no pair left" are no-ops:
+    // the loop is captured ONCE into a hipGraph of GRAPH_STEPS steps and replayed (launch-bound inner loop).
+    const unsigned upd_blocks = (unsigned)(w->S / 64) + 1; // 64 slots per wave + the compaction workgroup
+    const int dqp = (int)upd_groups(d);
+    const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16; // new centroid image; the p ring is static (48 KiB)
+    if (upd_lds > 100 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+    auto enqueue_step = [&](int64_t t, bool prof) {
+        hipLaunchKernelGGL(ward_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
+                           w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->st);
+        if (prof) {
+            icl_prof_scope ps(ctx, ICL_K_UPDATE, 3.0 * (double)(n - t - 1) * d, 4.0 * (double)(n - t - 1) * d + 4.0 * (double)(n - t - 1));
+            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
+                               w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
+        } else {
+            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
+                               w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
         }
-        {
-            icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 0.0);
-            hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(64), dim3(256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
-                               w->rescan, &w->st->rescan_n, (int64_t)0, w->st, w->rowmin, w->rownn);
+        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(32), dim3(n > 2048 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
+                           w->rescan, &w->st->rescan_n, (int64_t)0, w->st, w->rowmin, w->rownn, w->slot_id, w->id_slot);
+    };
+    const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
+    constexpr int GRAPH_STEPS = 64;
+    if (prof_update || T < 2 * GRAPH_STEPS) {
+        for (int64_t t = 0; t < T; ++t) enqueue_step(t, prof_update);
+    } else {
+        if (!w->graph_exec || w->graph_max_size != max_size) {
+            if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
+            w->graph_exec = nullptr;
+            hipGraph_t graph = nullptr;
+            ICL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            for (int g = 0; g < GRAPH_STEPS; ++g) enqueue_step(0, false);
+            ICL_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
+            hipError_t ge = hipGraphInstantiate(&w->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
+            w->graph_max_size = max_size;
         }
+        for (int64_t t = 0; t < T; t += GRAPH_STEPS) ICL_HIP(ctx, hipGraphLaunch(w->graph_exec, ctx->stream));
     }
     ICL_HIP(ctx, hipGetLastError());
     ICL_HIP(ctx, hipEventRecord(e2, ctx->stream));
