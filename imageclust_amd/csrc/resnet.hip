@@ -11,7 +11,7 @@
 // (or v_mfma_f32_32x32x2_f32 in parity mode) with the WEIGHTS as the MFMA A operand so that each lane ends up
 // holding 4 consecutive output channels of one pixel -> contiguous NHWC stores; BatchNorm (folded to
 // scale/shift), conv bias, residual add and ReLU are fused into the epilogue.  The 7x7/2 stem is lowered to the
-// same kernel through an im2col of the u8 image (K = 147 padded to 160), which also performs the reference's
+// same kernel through an im2col of the u8 image (K = 147 padded to 192), which also performs the reference's
 // RGB/255 scaling (embeddings.go:96).
 #include "icl_common.h"
 
@@ -29,7 +29,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct BF16 {
     typedef uint16_t elem;
     static constexpr int KE = 8;  // elements per 16-byte chunk
-    static constexpr int BK = 32; // elements per 64-byte LDS row
+    static constexpr int BK = 64; // elements per 128-byte LDS row
     __device__ static __forceinline__ float to_f(elem v) { return __uint_as_float((uint32_t)v << 16); }
     __device__ static __forceinline__ elem from_f(float f)
     {
@@ -47,7 +47,7 @@ struct BF16 {
 struct F32 {
     typedef float elem;
     static constexpr int KE = 4;
-    static constexpr int BK = 16;
+    static constexpr int BK = 32;
     __device__ static __forceinline__ float to_f(elem v) { return v; }
     __device__ static __forceinline__ elem from_f(float f) { return f; }
     __device__ static __forceinline__ void mma(const uint4 &w, const uint4 &x, f32x16 &acc)
@@ -68,45 +68,66 @@ struct conv_args {
     const void *R;      // residual, same shape as Y, or nullptr
     const float *scale; // [Cout] folded BN scale
     const float *shift; // [Cout] folded BN shift (+ conv bias)
+    const void *zero;   // >= 16 zero bytes: the source of padded taps / rows beyond M for the LDS-DMA loads
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int64_t M;          // B*Ho*Wo
     int K;              // KH*KW*Cin
+    int gx, gy;         // tiles along M and along Cout
 };
 
 #define CV_BM 128
+#define CV_ROWB 128 /* bytes per LDS row = one k-step of one tile row: 64 bf16 or 32 f32 */
 
-// LDS image of a [rows][64 B] tile: 16-byte slot s of row r lives at r*64 + ((s ^ ((r>>2)&3)) * 16).
-// A ds_read_b128 lane group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row fragment, same logical slot)
-// then touches 16 distinct 16-byte bank slots: conflict-free (MI355X_MICROARCH.md "LDS").
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+// LDS image of a [rows][128 B] tile: logical 16-byte slot s of row r lives at r*128 + ((s ^ ((r>>1)&7)) * 16).
+// ds_read_b128 serves fixed 16-lane groups (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row fragment, all
+// reading the same logical slot): the XOR spreads them over the 16 distinct 16-byte positions of two 256-byte bank
+// rows -> conflict-free (MI355X_MICROARCH.md "LDS").  The tile is filled by LDS-DMA, whose destination is
+// lane-linear (base + lane*16), so the swizzle is applied to each lane's SOURCE address (which k-chunk it fetches)
+// and again on the read: the same involution on both sides (cdna_hip_programming.md rule 21).
+__device__ __forceinline__ int lds_swz(int row, int slot) { return (slot ^ (row >> 1)) & 7; }
+
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s).  Give each XCD a contiguous
+// run of tiles with the Cout tile index fastest, so the workgroups that share an activation row-panel (and the
+// whole weight matrix) sit behind one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 {
     typedef typename T::elem elem;
-    constexpr int NT = BN / 64;        // 32-channel MFMA row tiles per wave
-    constexpr int WCH = BN / 64;       // weight chunks per thread per k-step (BN rows x 4 slots / 256)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BN + CV_BM) * 64];
-    constexpr int STAGE = (BN + CV_BM) * 64; // one pipeline stage: BN weight rows then CV_BM activation rows
+    constexpr int NT = BN / 64;                     // 32-channel MFMA row tiles per wave
+    constexpr int STAGE = (BN + CV_BM) * CV_ROWB;   // one pipeline stage: BN weight rows then CV_BM activation rows
+    constexpr int EP_LD = BN + 4;                   // fp32 epilogue tile row stride (floats)
+    constexpr int XI = CV_BM / 32;                  // activation LDS-DMA pieces per wave per stage (8 rows each)
+    constexpr int WI = BN / 32;                     // weight pieces per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 1, wn = wid >> 1;
-    const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
-    const int n0 = blockIdx.y * BN;
+    const int tile = xcd_remap(blockIdx.x, p.gx * p.gy);
+    const int64_t m0 = (int64_t)(tile / p.gy) * CV_BM;
+    const int n0 = (tile % p.gy) * BN;
     const elem *Xg = (const elem *)p.X;
     const elem *Wg = (const elem *)p.Wt;
 
-    // ---- per-thread staging roles (fixed for the whole K loop) ----
-    // activations: 2 chunks: rows (tid>>2) and 64+(tid>>2), slot tid&3
-    const int xslot = tid & 3;
-    int xrow[2];
-    int64_t xbase[2]; // element offset of pixel (b, oy*stride-pad, ox*stride-pad), channel 0
-    int xiy[2], xix[2];
-    bool xok[2];
+    // ---- per-lane LDS-DMA roles (fixed for the whole K loop) ----
+    // one piece = one wave-instruction = 8 tile rows x 128 B; lane -> (row = lane>>3, physical slot = lane&7)
+    const int prow = lane >> 3, ps = lane & 7;
+    int64_t xbase[XI];
+    int xiy[XI], xix[XI];
+    bool xok[XI];
+    int xls[XI]; // logical k-chunk this lane fetches for its row (source-side swizzle)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        xrow[i] = (tid >> 2) + 64 * i;
-        const int64_t m = m0 + xrow[i];
+    for (int i = 0; i < XI; ++i) {
+        const int row = wid * (CV_BM / 4) + i * 8 + prow;
+        const int64_t m = m0 + row;
         xok[i] = m < p.M;
         const int64_t mm = xok[i] ? m : 0;
         const int ox = (int)(mm % p.Wo);
@@ -116,9 +137,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         xiy[i] = oy * p.stride - p.pad;
         xix[i] = ox * p.stride - p.pad;
         xbase[i] = (((int64_t)b * p.H + xiy[i]) * p.W + xix[i]) * p.Cin;
+        xls[i] = lds_swz(row, ps);
     }
-    // weights: WCH chunks: rows (tid>>2) + 64*i, slot tid&3
-    const int64_t wbase = (int64_t)(n0 + (tid >> 2)) * p.K + xslot * T::KE;
+    int64_t wbase[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = wid * (BN / 4) + i * 8 + prow;
+        wbase[i] = (int64_t)(n0 + row) * p.K + lds_swz(row, ps) * T::KE;
+    }
 
     f32x16 acc[NT][2];
 #pragma unroll
@@ -128,17 +154,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    uint4 xr[2], wr[WCH];
-    int kh = 0, kw = 0, ci0 = 0, k0 = 0; // position of the k-step being LOADED
-    auto gload = [&]() {
-        const int64_t tap_off = ((int64_t)kh * p.W + kw) * p.Cin + ci0 + xslot * T::KE;
+    int kh = 0, kw = 0, ci0 = 0, k0 = 0; // position of the k-step being STAGED
+    auto stage = [&](int buf) {
+        unsigned char *wdst = smem + buf * STAGE + wid * (BN / 4) * CV_ROWB;
+        unsigned char *xdst = smem + buf * STAGE + BN * CV_ROWB + wid * (CV_BM / 4) * CV_ROWB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wg + wbase[i] + k0), (lptr_t)(wdst + i * 8 * CV_ROWB), 16, 0, 0);
+        const int64_t tap_off = ((int64_t)kh * p.W + kw) * p.Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
             const bool ok = xok[i] && (unsigned)(xiy[i] + kh) < (unsigned)p.H && (unsigned)(xix[i] + kw) < (unsigned)p.W;
-            xr[i] = ok ? *reinterpret_cast<const uint4 *>(Xg + xbase[i] + tap_off) : make_uint4(0, 0, 0, 0);
+            const elem *src = ok ? Xg + xbase[i] + tap_off + xls[i] * T::KE : (const elem *)p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xdst + i * 8 * CV_ROWB), 16, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) wr[i] = *reinterpret_cast<const uint4 *>(Wg + wbase + (int64_t)i * 64 * p.K + k0);
         // advance to the next k-step (uniform)
         k0 += T::BK;
         ci0 += T::BK;
@@ -150,87 +179,112 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
             }
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(smem + buf * STAGE + BN * 64 + lds_off(xrow[i], xslot)) = xr[i];
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4 *>(smem + buf * STAGE + lds_off((tid >> 2) + 64 * i, xslot)) = wr[i];
-    };
 
     const int nk = p.K / T::BK;
-    gload();
-    lstore(0);
-    __syncthreads();
+    stage(0);
+    __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
     const int fr = lane & 31, fh = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk) gload();
+        if (ks + 1 < nk) stage(cur ^ 1); // async: lands while this step's MFMAs run
+        const unsigned char *wsm = smem + cur * STAGE;
+        const unsigned char *xsm = wsm + BN * CV_ROWB;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 4; ++s) {
             uint4 wf[NT], xf[2];
 #pragma unroll
-            for (int a = 0; a < NT; ++a) wf[a] = *reinterpret_cast<const uint4 *>(smem + cur * STAGE + lds_off(wn * (BN / 2) + a * 32 + fr, 2 * s + fh));
+            for (int a = 0; a < NT; ++a) {
+                const int row = wn * (BN / 2) + a * 32 + fr;
+                wf[a] = *reinterpret_cast<const uint4 *>(wsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
+            }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4 *>(smem + cur * STAGE + BN * 64 + lds_off(wm * 64 + b * 32 + fr, 2 * s + fh));
+            for (int b = 0; b < 2; ++b) {
+                const int row = wm * 64 + b * 32 + fr;
+                xf[b] = *reinterpret_cast<const uint4 *>(xsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
+            }
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) T::mma(wf[a], xf[b], acc[a][b]);
         }
-        if (ks + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
+        __syncthreads(); // all reads of `cur` done, next stage landed
     }
 
-    // ---- epilogue: y = relu(acc*scale + shift (+ residual)) ; lane = pixel, 4 consecutive channels per store ----
-    elem *Yg = (elem *)p.Y;
-    const elem *Rg = (const elem *)p.R;
+    // ---- epilogue: y = relu(acc*scale + shift (+ residual)) ----
+    // accumulators (lane = pixel, 4 consecutive channels per register quad) -> fp32 LDS tile [pixel][channel] ->
+    // one 16-byte channel chunk per lane, so residual reads and output stores are whole contiguous rows; a lane's
+    // chunk column is fixed, so it needs only its own KE scale/shift values.
+    float *ep = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int64_t m = m0 + wm * 64 + b * 32 + fr;
-        if (m >= p.M) continue;
+        const int ml = wm * 64 + b * 32 + fr;
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
-                const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
-                const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
-                float v[4] = {acc[a][b][4 * g + 0] * sc.x + sh.x, acc[a][b][4 * g + 1] * sc.y + sh.y,
-                              acc[a][b][4 * g + 2] * sc.z + sh.z, acc[a][b][4 * g + 3] * sc.w + sh.w};
-                const int64_t off = m * p.Cout + n;
-                if (Rg) {
-                    if constexpr (sizeof(elem) == 2) {
-                        const uint2 rv = *reinterpret_cast<const uint2 *>(Rg + off);
-                        v[0] += T::to_f((elem)(rv.x & 0xffffu));
-                        v[1] += T::to_f((elem)(rv.x >> 16));
-                        v[2] += T::to_f((elem)(rv.y & 0xffffu));
-                        v[3] += T::to_f((elem)(rv.y >> 16));
-                    } else {
-                        const float4 rv = *reinterpret_cast<const float4 *>(Rg + off);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                    }
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
-                }
-                if constexpr (sizeof(elem) == 2) {
-                    uint2 o;
-                    o.x = (uint32_t)T::from_f(v[0]) | ((uint32_t)T::from_f(v[1]) << 16);
-                    o.y = (uint32_t)T::from_f(v[2]) | ((uint32_t)T::from_f(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(Yg + off) = o;
-                } else {
-                    *reinterpret_cast<float4 *>(Yg + off) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                const int nl = wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<float4 *>(ep + ml * EP_LD + nl) =
+                    make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
             }
+    }
+    __syncthreads();
+    elem *Yg = (elem *)p.Y;
+    const elem *Rg = (const elem *)p.R;
+    constexpr int CPR = BN / T::KE;   // 16-byte output chunks per tile row
+    constexpr int RPP = 256 / CPR;    // tile rows covered per pass
+    const int nl = (tid % CPR) * T::KE;
+    float sc[T::KE], sh[T::KE];
+#pragma unroll
+    for (int q = 0; q < T::KE; q += 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(p.scale + n0 + nl + q);
+        const float4 b4 = *reinterpret_cast<const float4 *>(p.shift + n0 + nl + q);
+        sc[q] = a4.x; sc[q + 1] = a4.y; sc[q + 2] = a4.z; sc[q + 3] = a4.w;
+        sh[q] = b4.x; sh[q + 1] = b4.y; sh[q + 2] = b4.z; sh[q + 3] = b4.w;
+    }
+#pragma unroll 2
+    for (int ml = tid / CPR; ml < CV_BM; ml += RPP) {
+        const int64_t m = m0 + ml;
+        if (m >= p.M) break;
+        float v[T::KE];
+#pragma unroll
+        for (int q = 0; q < T::KE; q += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(ep + ml * EP_LD + nl + q);
+            v[q] = t.x * sc[q] + sh[q];
+            v[q + 1] = t.y * sc[q + 1] + sh[q + 1];
+            v[q + 2] = t.z * sc[q + 2] + sh[q + 2];
+            v[q + 3] = t.w * sc[q + 3] + sh[q + 3];
+        }
+        const int64_t off = m * p.Cout + n0 + nl;
+        if (Rg) {
+            const uint4 rv = *reinterpret_cast<const uint4 *>(Rg + off);
+            const elem *re = reinterpret_cast<const elem *>(&rv);
+#pragma unroll
+            for (int q = 0; q < T::KE; ++q) v[q] += T::to_f(re[q]);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+        }
+        uint4 ov;
+        elem *oe = reinterpret_cast<elem *>(&ov);
+#pragma unroll
+        for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
+        *reinterpret_cast<uint4 *>(Yg + off) = ov;
     }
 }
 
+template <int BN>
+static constexpr size_t conv_lds_bytes()
+{
+    const size_t stages = 2 * (size_t)(BN + CV_BM) * CV_ROWB, ep = (size_t)CV_BM * (BN + 4) * 4;
+    return stages > ep ? stages : ep;
+}
+
 // ------------------------------------------------------------------------------------------------------------
-// K1 + stem lowering: u8 HWC RGB -> im2col rows [B*112*112][160] (k = (kh*7+kw)*3+c, zero padded), scaled by
+// K1 + stem lowering: u8 HWC RGB -> im2col rows [B*112*112][192] (k = (kh*7+kw)*3+c, zero padded), scaled by
 // float(1/255) exactly as BlobFromImage(scalefactor=1/255) does (embeddings.go:96).
 // ------------------------------------------------------------------------------------------------------------
-#define STEM_K 160
+#define STEM_K 192
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const uint8_t *__restrict__ img, int B, typename T::elem *__restrict__ out)
 {
@@ -348,6 +402,7 @@ struct icl_model {
     void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     void *im2col = nullptr;
     float *pooled = nullptr;
+    void *zero = nullptr; // 256 zero bytes: LDS-DMA source for padded taps
     int ws_batch = 0, ws_prec = -1;
 };
 
@@ -459,7 +514,7 @@ void icl_model_free(icl_ctx *ctx)
         for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift})
             if (p) (void)hipFree(p);
     }
-    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], m->im2col, (void *)m->pooled})
+    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], m->im2col, (void *)m->pooled, m->zero})
         if (p) (void)hipFree(p);
     delete m;
     ctx->model = nullptr;
@@ -534,6 +589,8 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
     ICL_TRY(upload(ctx, (void **)&m->fcw, p, (size_t)ICL_FC_OUT * ICL_FEAT_DIM * 4));
     p += (int64_t)ICL_FC_OUT * ICL_FEAT_DIM;
     ICL_TRY(upload(ctx, (void **)&m->fcb, p, (size_t)ICL_FC_OUT * 4));
+    ICL_HIP(ctx, hipMalloc(&m->zero, 256));
+    ICL_HIP(ctx, hipMemset(m->zero, 0, 256));
     return ICL_OK;
 }
 
@@ -589,14 +646,23 @@ static int ensure_ws(icl_ctx *ctx, int batch, int prec)
 }
 
 template <typename T>
-static int launch_conv_t(icl_ctx *ctx, const conv_args &a)
+static int launch_conv_t(icl_ctx *ctx, conv_args a)
 {
-    const unsigned gx = (unsigned)icl_ceil_div(a.M, CV_BM);
+    static bool attr_done = false;
+    if (!attr_done) { // opt in to > 64 KiB of dynamic LDS once per kernel instantiation
+        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<128>());
+        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<64>());
+        attr_done = true;
+    }
+    a.gx = (int)icl_ceil_div(a.M, CV_BM);
     icl_prof_scope ps(ctx, a.Cout % 128 == 0 ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
-    if (a.Cout % 128 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(gx, a.Cout / 128), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(gx, a.Cout / 64), dim3(256), 0, ctx->stream, a);
+    if (a.Cout % 128 == 0) {
+        a.gy = a.Cout / 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(), ctx->stream, a);
+    } else {
+        a.gy = a.Cout / 64;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<64>(), ctx->stream, a);
+    }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
 }
@@ -611,6 +677,7 @@ static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *
     a.R = R;
     a.scale = L.scale;
     a.shift = L.shift;
+    a.zero = ctx->model->zero;
     a.B = B;
     a.relu = relu;
     a.Cout = L.rec.cout;
@@ -650,7 +717,7 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
     if (!ctx || !x || !w || !scale || !shift || !y || B < 1 || H < 1 || k < 1 || stride < 1 || pad < 0)
         return icl_fail(ctx, ICL_ERR_ARG, "icl_conv2d_fused: bad argument");
     if (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) return icl_fail(ctx, ICL_ERR_ARG, "bad prec");
-    if (Cin % 32 || Cout % 64) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_conv2d_fused needs Cin %% 32 == 0 and Cout %% 64 == 0");
+    if (Cin % 64 || Cout % 64) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_conv2d_fused needs Cin %% 64 == 0 and Cout %% 64 == 0");
     const int Ho = (H + 2 * pad - k) / stride + 1;
     if (Ho < 1) return icl_fail(ctx, ICL_ERR_ARG, "empty output");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -673,9 +740,10 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
         }
         return ICL_OK;
     };
-    void *dx = nullptr, *dw = nullptr, *dr = nullptr, *dy = nullptr;
+    void *dx = nullptr, *dw = nullptr, *dr = nullptr, *dy = nullptr, *dz = nullptr;
     float *dsc = nullptr, *dsh = nullptr;
     int rc = to_dev(x, nx, &dx);
+    if (!rc && (hipMalloc(&dz, 256) != hipSuccess || hipMemset(dz, 0, 256) != hipSuccess)) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_conv2d_fused: zero page");
     if (!rc) rc = to_dev(wp.data(), nw, &dw);
     if (!rc && residual) rc = to_dev(residual, ny, &dr);
     if (!rc) rc = upload(ctx, (void **)&dsc, scale, (size_t)Cout * 4);
@@ -683,7 +751,7 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
     if (!rc && hipMalloc(&dy, ny * es) != hipSuccess) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_conv2d_fused: output alloc");
     if (!rc) {
         conv_args a;
-        a.X = dx; a.Wt = dw; a.Y = dy; a.R = dr; a.scale = dsc; a.shift = dsh;
+        a.X = dx; a.Wt = dw; a.Y = dy; a.R = dr; a.scale = dsc; a.shift = dsh; a.zero = dz;
         a.B = B; a.H = a.W = H; a.Cin = Cin; a.Ho = a.Wo = Ho; a.Cout = Cout; a.KH = a.KW = k; a.stride = stride; a.pad = pad;
         a.relu = relu; a.M = (int64_t)B * Ho * Ho; a.K = k * k * Cin;
         rc = prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
@@ -701,7 +769,7 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
         }
         if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_conv2d_fused: %s", hipGetErrorString(e));
     }
-    for (void *q : {dx, dw, dr, dy, (void *)dsc, (void *)dsh})
+    for (void *q : {dx, dw, dr, dy, dz, (void *)dsc, (void *)dsh})
         if (q) (void)hipFree(q);
     icl_prof_collect(ctx);
     return rc;

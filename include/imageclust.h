@@ -83,7 +83,7 @@ int icl_preprocess_u8(const uint8_t *hwc_rgb, float *nchw);
 int icl_set_batch(icl_ctx *ctx, int batch); /* embed batch size, 1..1024 */
 /* One fused convolution layer of the engine (the unit every ResNet50 conv is lowered to), host buffers:
  * y = relu?( conv(x, w) * scale[c] + shift[c] (+ residual) ).  x: [B][H][H][Cin] NHWC fp32, w: [Cout][Cin][k][k]
- * (OIHW, as in the ONNX initializer), residual / y: [B][Ho][Ho][Cout] NHWC fp32.  Needs Cin % 32 == 0 and
+ * (OIHW, as in the ONNX initializer), residual / y: [B][Ho][Ho][Cout] NHWC fp32.  Needs Cin % 64 == 0 and
  * Cout % 64 == 0.  Operands are rounded to bf16 when prec == ICL_PREC_BF16. */
 int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int Cin, const float *w, int Cout, int k,
                      int stride, int pad, const float *scale, const float *shift, const float *residual, int relu,

@@ -60,7 +60,7 @@ SHAPES = [(64, 64, 1, 1, 0, 56), (64, 64, 3, 1, 1, 56), (64, 256, 1, 1, 0, 56), 
           (256, 128, 1, 2, 0, 56), (128, 128, 3, 1, 1, 28), (128, 512, 1, 1, 0, 28), (256, 512, 1, 2, 0, 56),
           (512, 128, 1, 1, 0, 28), (512, 256, 1, 2, 0, 28), (256, 256, 3, 1, 1, 14), (256, 1024, 1, 1, 0, 14),
           (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14), (1024, 512, 1, 2, 0, 14), (512, 512, 3, 1, 1, 7),
-          (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14), (2048, 512, 1, 1, 0, 7), (160, 64, 1, 1, 0, 112)]
+          (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14), (2048, 512, 1, 1, 0, 7), (192, 64, 1, 1, 0, 112)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "c%d-%d_k%d_s%d_h%d" % (s[0], s[1], s[2], s[3], s[5]))
