@@ -10,9 +10,9 @@
 // per 256-thread workgroup, K staged through XOR-swizzled LDS in 64-byte row chunks, v_mfma_f32_32x32x16_bf16
 // (or v_mfma_f32_32x32x2_f32 in parity mode) with the WEIGHTS as the MFMA A operand so that each lane ends up
 // holding 4 consecutive output channels of one pixel -> contiguous NHWC stores; BatchNorm (folded to
-// scale/shift), conv bias, residual add and ReLU are fused into the epilogue.  The 7x7/2 stem is lowered to the
-// same kernel through an im2col of the u8 image (K = 147 padded to 192), which also performs the reference's
-// RGB/255 scaling (embeddings.go:96).
+// scale/shift), conv bias, residual add and ReLU are fused into the epilogue.  The 7x7/2 stem (stem_conv_kernel) shares
+// the MFMA step and the epilogue but gathers its A tile straight from the u8 image (K = 147 padded to 192), which also
+// performs the reference's RGB/255 scaling (embeddings.go:96).
 #include "icl_common.h"
 
 #include <algorithm>
@@ -33,11 +33,10 @@ struct BF16 {
     __device__ static __forceinline__ float to_f(elem v) { return __uint_as_float((uint32_t)v << 16); }
     __device__ static __forceinline__ elem from_f(float f)
     {
-        // round to nearest even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (elem)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (elem)(u >> 16);
+        // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN;
+        // MI355X_MICROARCH.md "Correctness boundaries")
+        const __bf16 h = (__bf16)f;
+        return __builtin_bit_cast(elem, h);
     }
     __device__ static __forceinline__ void mma(const uint4 &w, const uint4 &x, f32x16 &acc)
     {
@@ -98,13 +97,119 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// One k-step (128 bytes of K per tile row) of MFMAs from a staged LDS image: wsm = BN weight rows, xsm = 128 pixel rows.
+template <typename T, int BN>
+__device__ __forceinline__ void conv_mma_kstep(const unsigned char *wsm, const unsigned char *xsm, int wm, int wn, int fr, int fh,
+                                               f32x16 (&acc)[BN / 64][2])
+{
+    constexpr int NT = BN / 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        uint4 wf[NT], xf[2];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int row = wn * (BN / 2) + a * 32 + fr;
+            wf[a] = *reinterpret_cast<const uint4 *>(wsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int row = wm * 64 + b * 32 + fr;
+            xf[b] = *reinterpret_cast<const uint4 *>(xsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) T::mma(wf[a], xf[b], acc[a][b]);
+    }
+}
+
+// Epilogue: y = relu(acc*scale + shift (+ residual)).
+// accumulators (lane = pixel, 4 consecutive channels per register quad) -> fp32 LDS tile [pixel][channel] -> one
+// 16-byte channel chunk per lane, so residual reads and output stores are whole contiguous rows; a lane's chunk column
+// is fixed, so it needs only its own KE scale/shift values.  Callers must have finished reading the staged tiles.
+template <typename T, int BN, bool TILE2D = false>
+__device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char *smem, f32x16 (&acc)[BN / 64][2], int64_t m0, int n0,
+                                              int tid, int wm, int wn, int fr, int fh)
+{
+    // TILE2D (stem): tile row r is pixel (r/16, r%16) of an 8x16 patch whose top-left output pixel is m0
+    auto row_m = [&](int ml) -> int64_t { return TILE2D ? m0 + (int64_t)(ml >> 4) * p.Wo + (ml & 15) : m0 + ml; };
+    typedef typename T::elem elem;
+    constexpr int NT = BN / 64;
+    constexpr int EP_LD = BN + 4; // fp32 epilogue tile row stride (floats)
+    float *ep = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int ml = wm * 64 + b * 32 + fr;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<float4 *>(ep + ml * EP_LD + nl) =
+                    make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+    }
+    __syncthreads();
+    elem *Yg = (elem *)p.Y;
+    const elem *Rg = (const elem *)p.R;
+    constexpr int CPR = BN / T::KE;   // 16-byte output chunks per tile row
+    constexpr int RPP = 256 / CPR;    // tile rows covered per pass
+    constexpr int NPASS = CV_BM / RPP;
+    const int nl = (tid % CPR) * T::KE;
+    float sc[T::KE], sh[T::KE];
+#pragma unroll
+    for (int q = 0; q < T::KE; q += 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(p.scale + n0 + nl + q);
+        const float4 b4 = *reinterpret_cast<const float4 *>(p.shift + n0 + nl + q);
+        sc[q] = a4.x; sc[q + 1] = a4.y; sc[q + 2] = a4.z; sc[q + 3] = a4.w;
+        sh[q] = b4.x; sh[q + 1] = b4.y; sh[q + 2] = b4.z; sh[q + 3] = b4.w;
+    }
+    // all residual loads of the lane are issued before any arithmetic: NPASS x 16 B in flight per lane
+    uint4 rv[NPASS];
+    if (Rg) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int64_t m = row_m(tid / CPR + i * RPP);
+            rv[i] = m < p.M ? *reinterpret_cast<const uint4 *>(Rg + m * p.Cout + n0 + nl) : make_uint4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int ml = tid / CPR + i * RPP;
+        const int64_t m = row_m(ml);
+        if (m >= p.M) break;
+        float v[T::KE];
+#pragma unroll
+        for (int q = 0; q < T::KE; q += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(ep + ml * EP_LD + nl + q);
+            v[q] = t.x * sc[q] + sh[q];
+            v[q + 1] = t.y * sc[q + 1] + sh[q + 1];
+            v[q + 2] = t.z * sc[q + 2] + sh[q + 2];
+            v[q + 3] = t.w * sc[q + 3] + sh[q + 3];
+        }
+        if (Rg) {
+            const elem *re = reinterpret_cast<const elem *>(&rv[i]);
+#pragma unroll
+            for (int q = 0; q < T::KE; ++q) v[q] += T::to_f(re[q]);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+        }
+        uint4 ov;
+        elem *oe = reinterpret_cast<elem *>(&ov);
+#pragma unroll
+        for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
+        *reinterpret_cast<uint4 *>(Yg + m * p.Cout + n0 + nl) = ov;
+    }
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 {
     typedef typename T::elem elem;
     constexpr int NT = BN / 64;                     // 32-channel MFMA row tiles per wave
     constexpr int STAGE = (BN + CV_BM) * CV_ROWB;   // one pipeline stage: BN weight rows then CV_BM activation rows
-    constexpr int EP_LD = BN + 4;                   // fp32 epilogue tile row stride (floats)
     constexpr int XI = CV_BM / 32;                  // activation LDS-DMA pieces per wave per stage (8 rows each)
     constexpr int WI = BN / 32;                     // weight pieces per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,89 +293,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         const int cur = ks & 1;
         if (ks + 1 < nk) stage(cur ^ 1); // async: lands while this step's MFMAs run
         const unsigned char *wsm = smem + cur * STAGE;
-        const unsigned char *xsm = wsm + BN * CV_ROWB;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 wf[NT], xf[2];
-#pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                const int row = wn * (BN / 2) + a * 32 + fr;
-                wf[a] = *reinterpret_cast<const uint4 *>(wsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int row = wm * 64 + b * 32 + fr;
-                xf[b] = *reinterpret_cast<const uint4 *>(xsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) T::mma(wf[a], xf[b], acc[a][b]);
-        }
+        conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
         __syncthreads(); // all reads of `cur` done, next stage landed
     }
-
-    // ---- epilogue: y = relu(acc*scale + shift (+ residual)) ----
-    // accumulators (lane = pixel, 4 consecutive channels per register quad) -> fp32 LDS tile [pixel][channel] ->
-    // one 16-byte channel chunk per lane, so residual reads and output stores are whole contiguous rows; a lane's
-    // chunk column is fixed, so it needs only its own KE scale/shift values.
-    float *ep = reinterpret_cast<float *>(smem);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int ml = wm * 64 + b * 32 + fr;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
-                *reinterpret_cast<float4 *>(ep + ml * EP_LD + nl) =
-                    make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-            }
-    }
-    __syncthreads();
-    elem *Yg = (elem *)p.Y;
-    const elem *Rg = (const elem *)p.R;
-    constexpr int CPR = BN / T::KE;   // 16-byte output chunks per tile row
-    constexpr int RPP = 256 / CPR;    // tile rows covered per pass
-    const int nl = (tid % CPR) * T::KE;
-    float sc[T::KE], sh[T::KE];
-#pragma unroll
-    for (int q = 0; q < T::KE; q += 4) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(p.scale + n0 + nl + q);
-        const float4 b4 = *reinterpret_cast<const float4 *>(p.shift + n0 + nl + q);
-        sc[q] = a4.x; sc[q + 1] = a4.y; sc[q + 2] = a4.z; sc[q + 3] = a4.w;
-        sh[q] = b4.x; sh[q + 1] = b4.y; sh[q + 2] = b4.z; sh[q + 3] = b4.w;
-    }
-#pragma unroll 2
-    for (int ml = tid / CPR; ml < CV_BM; ml += RPP) {
-        const int64_t m = m0 + ml;
-        if (m >= p.M) break;
-        float v[T::KE];
-#pragma unroll
-        for (int q = 0; q < T::KE; q += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(ep + ml * EP_LD + nl + q);
-            v[q] = t.x * sc[q] + sh[q];
-            v[q + 1] = t.y * sc[q + 1] + sh[q + 1];
-            v[q + 2] = t.z * sc[q + 2] + sh[q + 2];
-            v[q + 3] = t.w * sc[q + 3] + sh[q + 3];
-        }
-        const int64_t off = m * p.Cout + n0 + nl;
-        if (Rg) {
-            const uint4 rv = *reinterpret_cast<const uint4 *>(Rg + off);
-            const elem *re = reinterpret_cast<const elem *>(&rv);
-#pragma unroll
-            for (int q = 0; q < T::KE; ++q) v[q] += T::to_f(re[q]);
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
-        }
-        uint4 ov;
-        elem *oe = reinterpret_cast<elem *>(&ov);
-#pragma unroll
-        for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
-        *reinterpret_cast<uint4 *>(Yg + off) = ov;
-    }
+    conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh);
 }
 
 template <int BN>
@@ -281,36 +307,110 @@ static constexpr size_t conv_lds_bytes()
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1 + stem lowering: u8 HWC RGB -> im2col rows [B*112*112][192] (k = (kh*7+kw)*3+c, zero padded), scaled by
-// float(1/255) exactly as BlobFromImage(scalefactor=1/255) does (embeddings.go:96).
+// Stem: conv0 7x7/2 p3 (3 -> 64) + BN + ReLU straight from the u8 image (K1 fused into the conv).
+// Implicit GEMM with K ordered (kh, 24-slot row): k = kh*24 + kw*3 + c for kw*3+c < 21, the 3 slots that pad each
+// filter row and the rows 168..191 carry ZERO weights.  With that order a 16-byte A chunk is KE consecutive BYTES of
+// one input row, so nothing ever straddles a filter row.  One workgroup = an 8x16 patch of output pixels (98 per
+// image, no ragged tiles): the 21 x 37-pixel u8 input patch is loaded once into LDS (zero outside the image = the
+// conv's zero padding), chunks are cut out of it with aligned ds_read_b32 + v_alignbyte, scaled by float(1/255) as
+// BlobFromImage does (embeddings.go:96), converted, and written into the swizzled LDS image the MFMA step reads.
 // ------------------------------------------------------------------------------------------------------------
 #define STEM_K 192
+#define STEM_ROWK 24         /* k slots per filter row (21 used) */
+#define STEM_PW 116          /* patch row stride in bytes: 37 pixels * 3 = 111, + slack for the padded slots, 4-aligned */
+#define STEM_PH 21
 template <typename T>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const uint8_t *__restrict__ img, int B, typename T::elem *__restrict__ out)
+__global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restrict__ img, const conv_args p)
 {
     typedef typename T::elem elem;
-    constexpr int CH = STEM_K / T::KE; // 16-byte chunks per row
-    const int64_t total = (int64_t)B * 112 * 112 * CH;
-    const float sc = (float)(1.0 / 255.0);
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(t % CH);
-        const int64_t m = t / CH;
-        const int ox = (int)(m % 112), oy = (int)((m / 112) % 112), b = (int)(m / (112 * 112));
-        elem v[T::KE];
+    constexpr int BN = 64;
+    constexpr int NKS = STEM_K / T::BK;            // k-steps: 3 (bf16) or 6 (f32)
+    constexpr int WST = BN * CV_ROWB;              // bytes of one weight k-step image
+    constexpr int XST = CV_BM * CV_ROWB;
+    constexpr int PATCH = STEM_PH * STEM_PW + 16;  // + slack: chunk reads run up to 11 bytes past a row's last pixel
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [NKS weight steps][2 activation buffers][patch]
+    unsigned char *patch = smem + NKS * WST + 2 * XST;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1;
+    const int tx = blockIdx.x % 7, ty = (blockIdx.x / 7) % 14;
+    const int64_t b = blockIdx.x / 98;
+    const int64_t m0 = (b * 112 + ty * 8) * 112 + tx * 16;
+    const elem *Wg = (const elem *)p.Wt;
+    // all weights (64 x 192) by LDS-DMA, once
+    {
+        const int prow = lane >> 3, ps = lane & 7;
 #pragma unroll
-        for (int e = 0; e < T::KE; ++e) {
-            const int k = ch * T::KE + e;
-            float f = 0.0f;
-            if (k < 147) {
-                const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
-                const int iy = oy * 2 - 3 + kh, ix = ox * 2 - 3 + kw;
-                if ((unsigned)iy < 224u && (unsigned)ix < 224u)
-                    f = (float)img[(((int64_t)b * 224 + iy) * 224 + ix) * 3 + c] * sc;
+        for (int j = 0; j < NKS; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wid * 16 + i * 8 + prow;
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wg + (int64_t)row * STEM_K + j * T::BK + lds_swz(row, ps) * T::KE),
+                                                 (lptr_t)(smem + j * WST + (wid * 16 + i * 8) * CV_ROWB), 16, 0, 0);
             }
-            v[e] = T::from_f(f);
-        }
-        *reinterpret_cast<uint4 *>(out + m * STEM_K + ch * T::KE) = *reinterpret_cast<const uint4 *>(v);
     }
+    // input patch: rows iy = ty*16-3 .. +20, byte columns (tx*32-3)*3 .. ; zero outside the image
+    {
+        const uint8_t *ib = img + b * (int64_t)ICL_IMG_BYTES;
+        const int iy0 = ty * 16 - 3, bx0 = (tx * 32 - 3) * 3;
+        for (int i = tid; i < PATCH; i += 256) {
+            const int pr = i / STEM_PW, pc = i - pr * STEM_PW;
+            const int iy = iy0 + pr, bx = bx0 + pc;
+            const bool ok = pr < STEM_PH && (unsigned)iy < 224u && (unsigned)bx < 672u;
+            patch[i] = ok ? ib[iy * 672 + bx] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+    // chunk roles: lane cuts the chunk (row, logical slot ls) for 4 tile rows; ls is fixed per lane
+    const int ls = tid & 7;
+    const float sc255 = (float)(1.0 / 255.0);
+    auto gather = [&](int j, int buf) {
+        const int k0 = j * T::BK + ls * T::KE;     // first k of the chunk; never straddles a filter row (24 % KE == 0)
+        const int kh = k0 / STEM_ROWK, r0 = k0 - kh * STEM_ROWK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const int oyl = row >> 4, oxl = row & 15;
+            elem v[T::KE];
+            if (kh < 7) {
+                const int addr = (oyl * 2 + kh) * STEM_PW + oxl * 6 + r0; // even: 0 or 2 mod 4
+                const uint32_t *w32 = reinterpret_cast<const uint32_t *>(patch + (addr & ~3));
+                const uint32_t d0 = w32[0], d1 = w32[1], d2 = w32[2];
+                const int sh = addr & 3;
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+#pragma unroll
+                for (int e = 0; e < T::KE; ++e) {
+                    const uint32_t byte = ((e < 4 ? lo : hi) >> (8 * (e & 3))) & 0xffu;
+                    v[e] = T::from_f((float)byte * sc255);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < T::KE; ++e) v[e] = T::from_f(0.0f);
+            }
+            *reinterpret_cast<uint4 *>(smem + NKS * WST + buf * XST + row * CV_ROWB + (lds_swz(row, ls) << 4)) = *reinterpret_cast<const uint4 *>(v);
+        }
+    };
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][bb][r] = 0.0f;
+    gather(0, 0);
+    __syncthreads(); // also drains the weight DMA
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NKS; ++j) {
+        if (j + 1 < NKS) gather(j + 1, (j + 1) & 1);
+        conv_mma_kstep<T, BN>(smem + j * WST, smem + NKS * WST + (j & 1) * XST, wm, wn, fr, fh, acc);
+        __syncthreads();
+    }
+    conv_epilogue<T, BN, true>(p, smem, acc, m0, 0, tid, wm, wn, fr, fh);
+}
+
+template <typename T>
+static constexpr size_t stem_lds_bytes()
+{
+    const size_t st = (size_t)(STEM_K / T::BK) * 64 * CV_ROWB + 2 * (size_t)CV_BM * CV_ROWB + STEM_PH * STEM_PW + 16, ep = (size_t)CV_BM * (64 + 4) * 4;
+    return st > ep ? st : ep;
 }
 
 // MaxPool 3x3/2 p1 (padding never wins), NHWC, one thread per 16-byte channel chunk of one output pixel.
@@ -400,7 +500,6 @@ struct icl_model {
     float *fcw = nullptr, *fcb = nullptr;
     // activation workspace
     void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    void *im2col = nullptr;
     float *pooled = nullptr;
     void *zero = nullptr; // 256 zero bytes: LDS-DMA source for padded taps
     int ws_batch = 0, ws_prec = -1;
@@ -514,7 +613,7 @@ void icl_model_free(icl_ctx *ctx)
         for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift})
             if (p) (void)hipFree(p);
     }
-    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], m->im2col, (void *)m->pooled, m->zero})
+    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], (void *)m->pooled, m->zero})
         if (p) (void)hipFree(p);
     delete m;
     ctx->model = nullptr;
@@ -569,8 +668,11 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
         for (int co = 0; co < cout; ++co)
             for (int c = 0; c < cin; ++c)
                 for (int a = 0; a < k; ++a)
-                    for (int b = 0; b < k; ++b)
-                        wf[(size_t)co * L.K + ((size_t)a * k + b) * cin + c] = W[(((size_t)co * cin + c) * k + a) * k + b];
+                    for (int b = 0; b < k; ++b) {
+                        // stem: filter rows padded to 24 k-slots (stem_conv_kernel); others: [kh][kw][cin]
+                        const size_t kk = (i == 0) ? (size_t)a * STEM_ROWK + (size_t)b * 3 + c : ((size_t)a * k + b) * cin + c;
+                        wf[(size_t)co * L.K + kk] = W[(((size_t)co * cin + c) * k + a) * k + b];
+                    }
         wb.resize(wf.size());
         for (size_t e = 0; e < wf.size(); ++e) wb[e] = host_bf16(wf[e]);
         ICL_TRY(upload(ctx, &L.w[ICL_PREC_FP32], wf.data(), wf.size() * 4));
@@ -626,9 +728,7 @@ static int ensure_ws(icl_ctx *ctx, int batch, int prec)
             (void)hipFree(b);
             b = nullptr;
         }
-    if (m->im2col) (void)hipFree(m->im2col);
     if (m->pooled) (void)hipFree(m->pooled);
-    m->im2col = nullptr;
     m->pooled = nullptr;
     m->ws_batch = 0;
     const size_t es = prec == ICL_PREC_BF16 ? 2 : 4;
@@ -637,8 +737,6 @@ static int ensure_ws(icl_ctx *ctx, int batch, int prec)
         hipError_t e = hipMalloc(&b, act);
         if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "activation workspace (%zu B): %s", act, hipGetErrorString(e));
     }
-    hipError_t e = hipMalloc(&m->im2col, (size_t)batch * 12544 * STEM_K * es);
-    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "im2col workspace: %s", hipGetErrorString(e));
     ICL_HIP(ctx, hipMalloc((void **)&m->pooled, (size_t)batch * ICL_FEAT_DIM * 4));
     m->ws_batch = batch;
     m->ws_prec = prec;
@@ -667,8 +765,7 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     return ICL_OK;
 }
 
-static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *X, void *Y, const void *R, int relu, int B,
-                       bool lowered_stem)
+static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *X, void *Y, const void *R, int relu, int B)
 {
     conv_args a;
     a.X = X;
@@ -681,20 +778,12 @@ static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *
     a.B = B;
     a.relu = relu;
     a.Cout = L.rec.cout;
-    if (lowered_stem) { // im2col rows as a 1x1 convolution over a 112x112x160 "image"
-        a.H = a.W = a.Ho = a.Wo = 112;
-        a.Cin = STEM_K;
-        a.KH = a.KW = 1;
-        a.stride = 1;
-        a.pad = 0;
-    } else {
-        a.H = a.W = L.rec.hin;
-        a.Ho = a.Wo = L.rec.hout;
-        a.Cin = L.rec.cin;
-        a.KH = a.KW = L.rec.k;
-        a.stride = L.rec.stride;
-        a.pad = L.rec.pad;
-    }
+    a.H = a.W = L.rec.hin;
+    a.Ho = a.Wo = L.rec.hout;
+    a.Cin = L.rec.cin;
+    a.KH = a.KW = L.rec.k;
+    a.stride = L.rec.stride;
+    a.pad = L.rec.pad;
     a.M = (int64_t)B * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Cin;
     const int bk = prec == ICL_PREC_BF16 ? BF16::BK : F32::BK;
@@ -783,10 +872,19 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     const int grid = 256 * 8;
     elem *x = (elem *)m->buf[0], *t1 = (elem *)m->buf[1], *t2 = (elem *)m->buf[2], *ds = (elem *)m->buf[3], *y = (elem *)m->buf[4];
     {
-        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (ICL_IMG_BYTES + 12544.0 * STEM_K * sizeof(elem)));
-        hipLaunchKernelGGL((stem_im2col_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, d_img, B, (elem *)m->im2col);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)stem_conv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds_bytes<T>());
+            attr_done = true;
+        }
+        conv_args a;
+        const conv_layer &L = m->conv[0];
+        a.X = nullptr; a.Wt = L.w[prec]; a.Y = y; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
+        a.B = B; a.H = a.W = 224; a.Cin = 3; a.Ho = a.Wo = 112; a.Cout = 64; a.KH = a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+        a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
+        icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
+        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3((unsigned)a.gx), dim3(256), stem_lds_bytes<T>(), ctx->stream, d_img, a);
     }
-    ICL_TRY(launch_conv(ctx, prec, m->conv[0], m->im2col, y, nullptr, 1, B, true));
     {
         icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
         hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, y, B, 112, 64, x);
@@ -795,14 +893,14 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     while (ci < m->nconv) {
         const conv_layer &c1 = m->conv[ci], &c2 = m->conv[ci + 1], &c3 = m->conv[ci + 2];
         const bool has_ds = c1.rec.block == 0;
-        ICL_TRY(launch_conv(ctx, prec, c1, x, t1, nullptr, 1, B, false));
-        ICL_TRY(launch_conv(ctx, prec, c2, t1, t2, nullptr, 1, B, false));
+        ICL_TRY(launch_conv(ctx, prec, c1, x, t1, nullptr, 1, B));
+        ICL_TRY(launch_conv(ctx, prec, c2, t1, t2, nullptr, 1, B));
         const void *res = x;
         if (has_ds) {
-            ICL_TRY(launch_conv(ctx, prec, m->conv[ci + 3], x, ds, nullptr, 0, B, false));
+            ICL_TRY(launch_conv(ctx, prec, m->conv[ci + 3], x, ds, nullptr, 0, B));
             res = ds;
         }
-        ICL_TRY(launch_conv(ctx, prec, c3, t2, y, res, 1, B, false)); // relu(bn(conv) + residual)
+        ICL_TRY(launch_conv(ctx, prec, c3, t2, y, res, 1, B)); // relu(bn(conv) + residual)
         std::swap(x, y);
         ci += has_ds ? 4 : 3;
     }

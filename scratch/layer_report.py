@@ -1,0 +1,35 @@
+import csv, sys
+tr=list(csv.DictReader(open(sys.argv[1])))
+ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name']) for r in tr]
+ev.sort()
+idx=[i for i,e in enumerate(ev) if e[2].startswith('void stem_im2col')]
+a,b=idx[1],idx[2]
+batch=ev[a:b]
+nblocks=[3,4,6,3]
+layers=[('conv0',192,64,1,112)]
+h=56;cin=64
+for s in range(4):
+    cout=256<<s; mid=cout//4
+    for bl in range(nblocks[s]):
+        stride=2 if (bl==0 and s>0) else 1
+        ho=h//stride
+        layers.append(('s%d.b%d.c1'%(s+1,bl),cin,mid,1,ho))
+        layers.append(('s%d.b%d.c2'%(s+1,bl),mid,mid,3,ho))
+        if bl==0: layers.append(('s%d.b%d.ds'%(s+1,bl),cin,cout,1,ho))
+        layers.append(('s%d.b%d.c3'%(s+1,bl),mid,cout,1,ho))
+        cin=cout;h=ho
+convs=[e for e in batch if 'conv_igemm' in e[2]]
+tot=0;totf=0;agg={}
+for (s,e,n),(name,ci,co,k,ho) in zip(convs,layers):
+    M=256*ho*ho; K=ci*k*k; fl=2*M*co*K; us=(e-s)/1e3
+    tot+=us;totf+=fl
+    key=(ci,co,k,ho)
+    agg.setdefault(key,[0,0,0]); agg[key][0]+=us; agg[key][1]+=fl; agg[key][2]+=1
+for key,(us,fl,c) in sorted(agg.items(), key=lambda kv:-kv[1][0]):
+    ci,co,k,ho=key
+    M=256*ho*ho
+    byt=(M*ci*(1 if k==1 else 1)+M*co*(2 if (k==1 and co>=256 and ci<co) else 1))*2*c  # rough: in + out (+res)
+    print("cin=%4d cout=%4d k=%d ho=%3d x%d  M=%7d K=%5d  %8.1f us  %6.1f TF/s  ~%5.2f TB/s  share %4.1f%%"%(ci,co,k,ho,c,M,ci*k*k,us,fl/us/1e6,byt/us/1e6,100*us/tot))
+print('total conv us',round(tot,1),'TF/s',round(totf/tot/1e6,1))
+print('other', [ (e[2][:30], round((e[1]-e[0])/1e3,1)) for e in batch if 'conv_igemm' not in e[2]])
+print('batch span us', (batch[-1][1]-batch[0][0])/1e3)
