@@ -88,6 +88,24 @@ __device__ __forceinline__ int lds_swz(int row, int slot) { return (slot ^ (row 
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
+// LDS-DMA piece issued from inline asm: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS byte address `lds_dst`
+// (M0 is written and restored inside the statement).  hipcc does not track it: unlike the builtin it puts no
+// vmcnt(0) in front of the next ds_read, so the transfer really overlaps the MFMAs of the current k-step; the
+// kernel waits for it itself (s_waitcnt vmcnt(0) + barrier) before the stage is read
+// (cdna_hip_programming.md 5.7 "LDS-DMA recipe").
+__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s).  Give each XCD a contiguous
 // run of tiles with the Cout tile index fastest, so the workgroups that share an activation row-panel (and the
 // whole weight matrix) sit behind one L2.  Bijective for any grid size.
@@ -260,18 +278,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     int kh = 0, kw = 0, ci0 = 0, k0 = 0; // position of the k-step being STAGED
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned wave_w = __builtin_amdgcn_readfirstlane(wid * (BN / 4) * CV_ROWB);
+    const unsigned wave_x = __builtin_amdgcn_readfirstlane(BN * CV_ROWB + wid * (CV_BM / 4) * CV_ROWB);
     auto stage = [&](int buf) {
-        unsigned char *wdst = smem + buf * STAGE + wid * (BN / 4) * CV_ROWB;
-        unsigned char *xdst = smem + buf * STAGE + BN * CV_ROWB + wid * (CV_BM / 4) * CV_ROWB;
+        const unsigned wdst = smem_base + buf * STAGE + wave_w;
+        const unsigned xdst = smem_base + buf * STAGE + wave_x;
 #pragma unroll
-        for (int i = 0; i < WI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Wg + wbase[i] + k0), (lptr_t)(wdst + i * 8 * CV_ROWB), 16, 0, 0);
+        for (int i = 0; i < WI; ++i) glds16_asm(Wg + wbase[i] + k0, wdst + i * 8 * CV_ROWB);
         const int64_t tap_off = ((int64_t)kh * p.W + kw) * p.Cin + ci0;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const bool ok = xok[i] && (unsigned)(xiy[i] + kh) < (unsigned)p.H && (unsigned)(xix[i] + kw) < (unsigned)p.W;
             const elem *src = ok ? Xg + xbase[i] + tap_off + xls[i] * T::KE : (const elem *)p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xdst + i * 8 * CV_ROWB), 16, 0, 0);
+            glds16_asm(src, xdst + i * 8 * CV_ROWB);
         }
         // advance to the next k-step (uniform)
         k0 += T::BK;
@@ -287,14 +307,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 
     const int nk = p.K / T::BK;
     stage(0);
-    __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of stage 0 have landed ...
+    __syncthreads();                                  // ... and so have everybody else's
     const int fr = lane & 31, fh = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < nk) stage(cur ^ 1); // async: lands while this step's MFMAs run
         const unsigned char *wsm = smem + cur * STAGE;
         conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
-        __syncthreads(); // all reads of `cur` done, next stage landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // next stage landed (this wave's pieces)
+        __syncthreads();                                  // all reads of `cur` done; all pieces of the next stage visible
     }
     conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh);
 }

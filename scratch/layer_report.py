@@ -2,11 +2,11 @@ import csv, sys
 tr=list(csv.DictReader(open(sys.argv[1])))
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name']) for r in tr]
 ev.sort()
-idx=[i for i,e in enumerate(ev) if e[2].startswith('void stem_im2col')]
+idx=[i for i,e in enumerate(ev) if e[2].startswith("void stem_conv")]
 a,b=idx[1],idx[2]
 batch=ev[a:b]
 nblocks=[3,4,6,3]
-layers=[('conv0',192,64,1,112)]
+layers=[]
 h=56;cin=64
 for s in range(4):
     cout=256<<s; mid=cout//4
