@@ -30,6 +30,8 @@ struct icl_ward_ws; // ward.hip
 struct icl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream: work forked beside `stream` inside captured graphs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mu;
     std::string err;
     hipDeviceProp_t prop;

@@ -53,6 +53,13 @@ extern "C" int icl_create(int device, icl_ctx **out)
         delete c;
         return icl_fail(nullptr, ICL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return icl_fail(nullptr, ICL_ERR_HIP, "icl_create: side stream / events");
+    }
     *out = c;
     return ICL_OK;
 }
@@ -70,6 +77,9 @@ extern "C" void icl_destroy(icl_ctx *ctx)
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 

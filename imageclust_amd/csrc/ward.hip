@@ -24,12 +24,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct ward_state {
     int32_t done;      // no mergeable pair left (clustering.go:222-225)
     int32_t t;         // merges performed so far
-    int32_t rescan_n;  // rows queued for a (min,argmin) rescan
     int32_t cur_a, cur_b, cur_c; // creation ids: merged pair (a = higher position) and the new cluster
     int32_t cur_valid; // the current step performed a merge
     int32_t target;    // merges to perform: N - k (clustering.go:220); further steps are no-ops
     int32_t nlive;     // live clusters occupy the dense slot range [0, nlive)
     int32_t mv_from, mv_to; // slot compaction of the current step: cluster in slot mv_from moves to mv_to (-1: none)
+    int32_t pre_row, pre_nn; // preselection: best pair among all rows except the newest cluster's (-1: none)
+    float pre_val;
     int32_t pad;
     unsigned long long ckey; // (value bits << 32 | column id) minimum of the new cluster's row, built with atomicMin
 };
@@ -50,7 +51,6 @@ struct icl_ward_ws {
     float *Dtri = nullptr;
     int64_t dtri_floats = 0;
     int32_t *merges = nullptr; // [2*N]
-    int32_t *rescan = nullptr; // [M]
     ward_state *st = nullptr;
     // find_closest scratch
     float *fc_min = nullptr;
@@ -68,7 +68,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
-                    w->merges, w->rescan, w->st, w->fc_min, w->fc_nn, w->fc_out};
+                    w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out};
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -275,25 +275,29 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
     bi = -1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
     const int64_t nvec = aligned ? (len >> 2) : 0;
-    // 4 columns per load, 2 loads (+ their masks) in flight per lane; a lane visits its columns in ascending order
-    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 2 * (int64_t)blockDim.x) {
-        const int64_t q1 = q0 + blockDim.x;
-        const bool has1 = q1 < nvec;
-        const float4 va = reinterpret_cast<const float4 *>(row)[q0];
-        const float4 vb = has1 ? reinterpret_cast<const float4 *>(row)[q1] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
-        int4 ma = make_int4(1, 1, 1, 1), mb = make_int4(1, 1, 1, 1);
-        if (asz) {
-            ma = reinterpret_cast<const int4 *>(asz)[q0];
-            if (has1) mb = reinterpret_cast<const int4 *>(asz)[q1];
-        }
-        const float vv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const int mm[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+    // 4 columns per load, 4 loads (+ their masks) in flight per lane; a lane visits its columns in ascending order
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        float4 v[4];
+        int4 m[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = asz ? (mm[e] > 0 && mm[e] + my_size <= max_size) : true;
-            if (ok && vv[e] < bv) {
-                bv = vv[e];
-                bi = (int)((e < 4 ? q0 : q1) * 4 + (e & 3));
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const bool has = q < nvec;
+            v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            m[j] = (has && asz) ? reinterpret_cast<const int4 *>(asz)[q] : make_int4(1, 1, 1, 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            const int mm[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = asz ? (mm[e] > 0 && mm[e] + my_size <= max_size) : true;
+                if (ok && vv[e] < bv) {
+                    bv = vv[e];
+                    bi = (int)(q * 4 + e);
+                }
             }
         }
     }
@@ -309,35 +313,14 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
     }
 }
 
-// rows: explicit list (list != nullptr, *count entries) or 0..nrows-1.  Packed triangle addressing.
+// Initial row caches: one workgroup per row r of the packed triangle (columns 0..r-1).
 __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
-                                                            const int32_t *__restrict__ asz, int max_size,
-                                                            const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                            int64_t nrows, ward_state *__restrict__ st,
-                                                            float *__restrict__ rowmin, int32_t *__restrict__ rownn,
-                                                            int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot)
+                                                             const int32_t *__restrict__ asz, int max_size, int64_t nrows,
+                                                             float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
-    if (st && (st->done || !st->cur_valid)) return;
-    if (st && blockIdx.x == 0 && threadIdx.x == 0) {
-        // the update kernel reduced the new cluster's row with atomicMin on (value bits, column): publish it
-        const unsigned long long key = st->ckey;
-        const int c = st->cur_c;
-        rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
-        rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
-        // slot compaction: the update kernel copied the centroid in slot mv_from to the freed slot mv_to
-        if (st->mv_to >= 0) {
-            const int y = slot_id[st->mv_from];
-            slot_id[st->mv_to] = y;
-            id_slot[y] = st->mv_to;
-            slot_id[st->mv_from] = -1;
-        }
-        st->nlive = st->nlive - 1;
-    }
-    const int64_t total = list ? (int64_t)(*count) : nrows;
-    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
-        const int64_t r = list ? list[idx] : idx;
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
         const int my = asz[r];
         float bv;
         int bi;
@@ -412,12 +395,13 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
     if (i == 0) {
         st->done = 0;
         st->t = 0;
-        st->rescan_n = 0;
         st->cur_a = st->cur_b = st->cur_c = -1;
         st->cur_valid = 0;
         st->target = target;
         st->nlive = (int32_t)n;
         st->mv_from = st->mv_to = -1;
+        st->pre_row = st->pre_nn = -1;
+        st->pre_val = ICL_MAXF;
         st->ckey = ~0ull;
     }
 }
@@ -460,56 +444,146 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     }
 }
 
-// Step 1/3: pick the globally closest admissible pair and create the merged cluster.
-__global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT,
-                                                          float *__restrict__ Crow, float *__restrict__ cnew,
-                                                          int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot,
-                                                          int32_t *__restrict__ asz, float *__restrict__ rowmin,
-                                                          const int32_t *__restrict__ rownn, int32_t *__restrict__ merges,
+// ---- one merge step = { update(t-1) || preselect(t) } -> finish(t) ------------------------------------------------
+//
+// preselect(t): the lexicographic minimum of (cached value, row) over the row caches of every row EXCEPT the cluster
+// created by merge t-1 (its cache is still MaxFloat32 while its row is being computed).  It touches nothing the
+// update kernel writes (row c of Dtri, st->ckey, CT4/Crow of the compaction target), so the two run CONCURRENTLY on
+// the same launch: preselect(t+1) is ONE extra workgroup of the update(t) grid.
+// Caches are LAZY: when a row's cached partner dies the row is not rescanned; its cached value stays a valid LOWER
+// bound (a row only ever loses entries), so it is rescanned only if it reaches the top of the selection -- then its
+// exact (min, argmin) replaces the bound and the selection is repeated.  When the winner is clean, every other row's
+// bound is lexicographically >= it, hence so is its true minimum: the pick equals the reference's full scan
+// (clustering.go:119-133), ties included.
+__device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
+                                               int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
+                                               const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st,
+                                               float *sv, int *si, int *sh)
+{
+    if (st->done) return;
+    const int t = st->t;
+    if (t >= st->target) return;
+    const int64_t nvec = (n + t + 3) >> 2; // rowmin is padded with MaxFloat32 up to a multiple of 4
+    float bv;
+    int bi;
+    for (;;) {
+        // rows are read 4 at a time, 4 loads in flight per lane, ascending row order per lane
+        bv = ICL_MAXF;
+        bi = -1;
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (e[i] < bv) { // strict: first row wins among equal minima (clustering.go:125)
+                        bv = e[i];
+                        bi = (int)(q * 4 + i);
+                    }
+            }
+        }
+        block_argmin(bv, bi, sv, si);
+        if (bi < 0) break;
+        if (threadIdx.x == 0) {
+            const int nn = rownn[bi];
+            sh[0] = asz[nn] > 0 ? 0 : 1; // cached partner dead -> the cached value is only a bound
+            sh[1] = nn;
+        }
+        __syncthreads();
+        const int dirty = sh[0];
+        __syncthreads();
+        if (!dirty) break;
+        float rv;
+        int ri;
+        scan_row(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, rv, ri);
+        block_argmin(rv, ri, sv, si);
+        if (threadIdx.x == 0) {
+            rowmin[bi] = rv;
+            rownn[bi] = ri;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->pre_row = bi;
+        st->pre_nn = bi >= 0 ? sh[1] : -1;
+        st->pre_val = bv;
+    }
+}
+
+// preselect(0): before the first merge there is no update to run beside.
+__global__ __launch_bounds__(1024) void ward_presel_kernel(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
+                                                          int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
+                                                          const int64_t *__restrict__ rowoff, int max_size,
                                                           ward_state *__restrict__ st)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
+    __shared__ int sh[2];
+    ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+}
+
+// finish(t), ONE workgroup: (a) publish the row cache of the cluster created by merge t-1 (its minimum was reduced by
+// the update kernel with atomicMin) and apply the slot compaction it scheduled; (b) the winner of merge t is that
+// row's pair if its value is STRICTLY below the preselected one (the newest cluster has the largest row index, so
+// it loses ties), else the preselected pair; (c) bookkeeping of MergeClusters / RemoveClusters (clustering.go:29-58,
+// :240-241) and the merged centroid (:37-40).
+__global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT,
+                                                          float *__restrict__ Crow, float *__restrict__ cnew,
+                                                          int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot,
+                                                          int32_t *__restrict__ asz, float *__restrict__ rowmin,
+                                                          int32_t *__restrict__ rownn, int32_t *__restrict__ merges,
+                                                          ward_state *__restrict__ st)
+{
     __shared__ int sh[6];
     if (st->done) return;
     const int t = st->t;
-    if (t >= st->target) { // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
-        if (threadIdx.x == 0) st->cur_valid = 0;
-        return;
-    }
-    // lexicographic (value, row) minimum over the row caches; rows are read 4 at a time, 4 loads in flight per lane
-    const int64_t nvec = (n + t + 3) >> 2; // rowmin is padded with MaxFloat32 up to a multiple of 4
-    float bv = ICL_MAXF;
-    int bi = -1;
-    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
-        float4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t q = q0 + (int64_t)j * blockDim.x;
-            v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t q = q0 + (int64_t)j * blockDim.x;
-            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (e[i] < bv) { // strict: first row wins among equal minima (clustering.go:125)
-                    bv = e[i];
-                    bi = (int)(q * 4 + i);
-                }
-        }
-    }
-    block_argmin(bv, bi, sv, si);
     if (threadIdx.x == 0) {
-        if (bi < 0) {
-            st->done = 1; // clustering.go:222-225 "No more clusters to merge."
-            st->cur_valid = 0;
-            st->rescan_n = 0;
-            sh[0] = -1;
+        float cv = ICL_MAXF;
+        int cx = -1, c = -1;
+        if (st->cur_valid) {
+            const unsigned long long key = st->ckey;
+            c = st->cur_c;
+            if (key != ~0ull) {
+                cv = __uint_as_float((unsigned)(key >> 32));
+                cx = (int)(key & 0xffffffffu);
+            }
+            rowmin[c] = cv;
+            rownn[c] = cx;
+            if (st->mv_to >= 0) { // the update kernel copied the centroid in slot mv_from to the freed slot mv_to
+                const int y = slot_id[st->mv_from];
+                slot_id[st->mv_to] = y;
+                id_slot[y] = st->mv_to;
+                slot_id[st->mv_from] = -1;
+            }
+            st->nlive = st->nlive - 1;
+        }
+        int a = -1, b = -1;
+        if (t < st->target) {
+            const float pv = st->pre_val;
+            const int pr = st->pre_row;
+            if (cx >= 0 && (pr < 0 || cv < pv)) { // strict '<': on equal values the lower row index (pr < c) wins
+                a = c;
+                b = cx;
+            } else if (pr >= 0) {
+                a = pr;
+                b = st->pre_nn;
+            }
+            if (a < 0) {
+                st->done = 1; // clustering.go:222-225 "No more clusters to merge."
+                st->cur_valid = 0;
+            }
         } else {
-            const int a = bi, b = rownn[bi];
-            sh[0] = a;
+            st->cur_valid = 0; // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
+        }
+        sh[0] = a;
+        if (a >= 0) {
             sh[1] = b;
             sh[2] = asz[a];
             sh[3] = asz[b];
@@ -550,7 +624,6 @@ __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int
         const int last = st->nlive - 1; // keep live slots dense: the cluster in the last slot moves into b's slot
         st->mv_from = slot_b != last ? last : -1;
         st->mv_to = slot_b != last ? slot_b : -1;
-        st->rescan_n = 0;
         st->ckey = ~0ull;
         st->cur_a = a;
         st->cur_b = b;
@@ -560,42 +633,52 @@ __global__ __launch_bounds__(1024) void ward_select_kernel(int64_t n, int d, int
     }
 }
 
-// Step 2/3 (K8 exact): WardDistance(x, new) from centroids (clustering.go:84) for every live cluster x, sequential
+// update(t) (K8 exact): WardDistance(x, new) from centroids (clustering.go:84) for every live cluster x, sequential
 // k, unfused fp32, written into the new cluster's row.  Algorithmic traffic: 4*n_live*D bytes per merge.
 //
 // The sum over k must be accumulated strictly in order (the reference's loop), i.e. one DEPENDENT fp32 add per k per
 // cluster: ~3 ns each on gfx950, a 6.3 us floor for D = 2048 that no amount of bandwidth removes.  Measured
 // (scratch/chain_bench.hip): a lone wave issues ~1 instruction per 2.3 ns, so a wave that also loads, subtracts and
-// squares spends 9-18 ns per k.  Hence the split: a workgroup of 4 waves owns 64 slots; waves 1-3 (producers) stream
+// squares spends 9-18 ns per k.  Hence the split: a workgroup of 7 waves owns 64 slots; waves 1-6 (producers) stream
 // the slots' centroids as dwordx4 from the CT4 layout, compute p_k = (x_k - c_k)^2 and hand whole stages of p to wave 0
 // through a double-buffered LDS ring; wave 0 (the chain) only does ds_read_b128 + four dependent v_add_f32 per 4 k.
 // One barrier per stage of 96 k.  Live slots are kept dense ([0, nlive)): the last workgroup copies the centroid of
 // the last live slot into the slot freed by this merge.  The new row's minimum is folded in with one 64-bit
-// atomicMin per workgroup; rows whose cached argmin just died are queued for a rescan.
-#define UPD_P 3                       /* producer waves */
-#define UPD_GP 8                      /* k-groups (float4) per producer per stage */
+// atomicMin per workgroup.
+#define UPD_P 6                       /* producer waves */
+#define UPD_GP 4                      /* k-groups (float4) per producer per stage */
+#define UPD_THREADS (64 * (UPD_P + 1))
 #define UPD_SG (UPD_P * UPD_GP)       /* k-groups per stage */
-#define UPD_PAD_G UPD_SG              /* zero groups past the end so the last prefetch needs no guard */
-static inline int64_t upd_groups(int d) { return (((int64_t)d + 3) / 4 + 2 * UPD_SG - 1) / (2 * UPD_SG) * (2 * UPD_SG); }
+#define UPD_PAD_G (2 * UPD_SG)        /* zero groups past the end so the last prefetches need no guard */
+static inline int64_t upd_groups(int d) { return (((int64_t)d + 3) / 4 + 3 * UPD_SG - 1) / (3 * UPD_SG) * (3 * UPD_SG); }
 
-__global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+__global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                float *__restrict__ Crow, const float *__restrict__ cnew,
                                                                const int32_t *__restrict__ slot_id,
                                                                const int32_t *__restrict__ asz, const int32_t *__restrict__ rownn,
                                                                const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
-                                                               int32_t *__restrict__ rescan, ward_state *__restrict__ st,
-                                                               int max_size)
+                                                               ward_state *__restrict__ st,
+                                                               int max_size, int64_t n, float *__restrict__ rowmin,
+                                                               int32_t *__restrict__ rownn_w)
 {
     __shared__ float4 ring[2][UPD_SG][64]; // 48 KiB
+    if (blockIdx.x == gridDim.x - 2) { // preselect(t+1) rides along as one workgroup: it never touches row c / ckey
+        float *sv = reinterpret_cast<float *>(&ring[0][0][0]);
+        int *si = reinterpret_cast<int *>(sv + 16);
+        int *sh = si + 16;
+        ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, max_size, st, sv, si, sh);
+        return;
+    }
     if (st->done || !st->cur_valid) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: role and addresses stay scalar
     if (blockIdx.x == gridDim.x - 1) { // compaction copy (disjoint from every column read below: mv_to is a free slot)
         const int from = st->mv_from, to = st->mv_to;
         if (to < 0) return;
         const int dq = (d + 3) >> 2;
-        for (int g = threadIdx.x; g < dq; g += 256)
+        for (int g = threadIdx.x; g < dq; g += UPD_THREADS)
             *reinterpret_cast<float4 *>(CT + ct4_off(g, S, to)) = *reinterpret_cast<const float4 *>(CT + ct4_off(g, S, from));
-        for (int k = threadIdx.x; k < d; k += 256) Crow[(int64_t)to * d + k] = Crow[(int64_t)from * d + k];
+        for (int k = threadIdx.x; k < d; k += UPD_THREADS) Crow[(int64_t)to * d + k] = Crow[(int64_t)from * d + k];
         return;
     }
     const int nlive = st->nlive;
@@ -606,39 +689,37 @@ __global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int dqp, 
     bool live = x >= 0 && x != c;
     const int sx = live ? asz[x] : 0;
     live = live && sx > 0;
-    if (live && wave == 0) {
-        const int nn = rownn[x];
-        if (nn == a || nn == b) {
-            const int pos = atomicAdd(&st->rescan_n, 1);
-            rescan[pos] = x;
-        }
-    }
     const int sc = asz[c];
     const bool act = live && (sx + sc <= max_size); // else: banned for good (static mask); value never read
     if (!__any(act)) return;                         // same 64 slots in every wave: a workgroup-uniform exit
     // CT4 and cnew carry dqp + UPD_PAD_G zero-padded groups: padded k contribute (0-0)^2 = +0 exactly and no load
     // in the pipeline needs a guard.
-    const float4 *col = reinterpret_cast<const float4 *>(CT) + slot;
+    // column loads use a scalar row base + one per-lane 32-bit byte offset (the CT4 image is < 4 GiB)
+    const char *ctb = reinterpret_cast<const char *>(CT);
+    const unsigned voff = (unsigned)slot * 16u;
+    const int64_t row_bytes = S * 16;
     // the new centroid is staged once into LDS: scalar loads would share lgkmcnt with the ring's ds_writes and, being
     // unordered against them, force lgkmcnt(0) (a full LDS round trip) on every k-group
     extern __shared__ __attribute__((aligned(16))) float4 cn4[];
-    for (int g = threadIdx.x; g < dqp + UPD_PAD_G; g += 256) cn4[g] = reinterpret_cast<const float4 *>(cnew)[g];
+    for (int g = threadIdx.x; g < dqp + UPD_PAD_G; g += UPD_THREADS) cn4[g] = reinterpret_cast<const float4 *>(cnew)[g];
     __syncthreads();
     const int pj = wave - 1;
     float s = 0.0f;
-    float4 va[UPD_GP], vb[UPD_GP];
+    float4 va[UPD_GP], vb[UPD_GP], vc[UPD_GP];
     auto load = [&](float4 (&v)[UPD_GP], int stage) {
-        const int g0 = stage * UPD_SG + pj * UPD_GP;
+        const char *rb = ctb + (int64_t)(stage * UPD_SG + pj * UPD_GP) * row_bytes; // wave-uniform
 #pragma unroll
-        for (int u = 0; u < UPD_GP; ++u) v[u] = col[(int64_t)(g0 + u) * S];
+        for (int u = 0; u < UPD_GP; ++u) v[u] = *reinterpret_cast<const float4 *>(rb + (int64_t)u * row_bytes + voff);
     };
     auto produce = [&](const float4 (&v)[UPD_GP], int stage, int buf) {
         const int g0 = stage * UPD_SG + pj * UPD_GP;
 #pragma unroll
         for (int u = 0; u < UPD_GP; ++u) {
             const float4 cv = cn4[g0 + u]; // broadcast ds_read_b128
-            const float d0 = v[u].x - cv.x, d1 = v[u].y - cv.y, d2 = v[u].z - cv.z, d3 = v[u].w - cv.w; // :139 via :84
-            ring[buf][pj * UPD_GP + u][lane] = make_float4(d0 * d0, d1 * d1, d2 * d2, d3 * d3);       // :154 products
+            const f2 xa = {v[u].x, v[u].y}, xb = {v[u].z, v[u].w}, ca = {cv.x, cv.y}, cb = {cv.z, cv.w};
+            const f2 da = xa - ca, db = xb - cb; // clustering.go:139 via :84 (v_pk_add_f32 with neg)
+            const f2 pa = da * da, pb = db * db; // :154 products, each rounded (v_pk_mul_f32)
+            ring[buf][pj * UPD_GP + u][lane] = make_float4(pa.x, pa.y, pb.x, pb.y);
         }
     };
     auto consume = [&](int buf) {
@@ -651,21 +732,32 @@ __global__ __launch_bounds__(256) void ward_update_exact_kernel(int d, int dqp, 
             s = s + p.w;
         }
     };
-    const int nstage = dqp / UPD_SG; // even
-    if (wave > 0) load(va, 0);
-    for (int i = 0; i < nstage; i += 2) {
+    // producers keep TWO stages of column loads in flight (3 register sets) so a stage's arithmetic never waits on
+    // the memory latency; the p ring in LDS is double-buffered (stage parity)
+    const int nstage = dqp / UPD_SG; // multiple of 3
+    if (wave > 0) {
+        load(va, 0);
+        load(vb, 1);
+    }
+    for (int i = 0; i < nstage; i += 3) {
         if (wave > 0) {
-            load(vb, i + 1);
-            produce(va, i, 0);
+            load(vc, i + 2);
+            produce(va, i, i & 1);
         }
         __syncthreads();
-        if (wave == 0) consume(0);
+        if (wave == 0) consume(i & 1);
         if (wave > 0) {
-            load(va, i + 2); // i+2 == nstage on the last pass: zero padding
-            produce(vb, i + 1, 1);
+            load(va, i + 3); // stages >= nstage: zero padding
+            produce(vb, i + 1, (i + 1) & 1);
         }
         __syncthreads();
-        if (wave == 0) consume(1);
+        if (wave == 0) consume((i + 1) & 1);
+        if (wave > 0) {
+            load(vb, i + 4);
+            produce(vc, i + 2, i & 1);
+        }
+        __syncthreads();
+        if (wave == 0) consume(i & 1);
     }
     if (wave != 0) return;
     const float num = (float)((int64_t)sx * (int64_t)sc);
@@ -696,13 +788,13 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
-                        w->merges, w->rescan, w->st};
+                        w->merges, w->st};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
         w->graph_exec = nullptr;
         w->CT = w->Crow = w->cnew = w->rowmin = w->Dtri = nullptr;
-        w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = w->rescan = nullptr;
+        w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = nullptr;
         w->rowoff = nullptr;
         w->st = nullptr;
         w->capN = 0;
@@ -739,7 +831,6 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rowoff, int64_t, w->M + 1);
         WS_ALLOC(Dtri, float, w->dtri_floats);
         WS_ALLOC(merges, int32_t, 2 * n + 2);
-        WS_ALLOC(rescan, int32_t, w->M);
         WS_ALLOC(st, ward_state, 1);
         ICL_HIP(ctx, hipMemcpyAsync(w->rowoff, w->h_rowoff.data(), (size_t)(w->M + 1) * sizeof(int64_t),
                                     hipMemcpyHostToDevice, ctx->stream));
@@ -976,35 +1067,41 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
         hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, n, (ward_state *)nullptr, w->rowmin, w->rownn,
-                           w->slot_id, w->id_slot);
+                           n, w->rowmin, w->rownn);
         ICL_HIP(ctx, hipGetLastError());
     }
     ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
 
-    // Merge loop: T steps of {select, update, rescan}.  Every step-varying quantity lives in device memory
+    // Merge loop: preselect(0), finish(0), then T steps of { update(t) with preselect(t+1) riding along } -> finish(t+1).  Every step-varying quantity lives in device memory
     // (ward_state), so the launches are identical and steps past the target / past "no pair left" are no-ops:
     // the loop is captured ONCE into a hipGraph of GRAPH_STEPS steps and replayed (launch-bound inner loop).
-    const unsigned upd_blocks = (unsigned)(w->S / 64) + 1; // 64 slots per wave + the compaction workgroup
+    const unsigned upd_blocks = (unsigned)(w->S / 64) + 2; // 64 slots per workgroup + preselect + compaction workgroups
     const int dqp = (int)upd_groups(d);
     const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16; // new centroid image; the p ring is static (48 KiB)
     if (upd_lds > 100 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
-    auto enqueue_step = [&](int64_t t, bool prof) {
-        hipLaunchKernelGGL(ward_select_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
+    auto finish = [&]() {
+        hipLaunchKernelGGL(ward_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
                            w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->st);
+    };
+    auto launch_update = [&]() {
+        hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(UPD_THREADS), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
+                           w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+    };
+    // one step: update(t) [with preselect(t+1) as one of its workgroups] -> finish(t+1)
+    auto enqueue_step = [&](int64_t t, bool prof) {
         if (prof) {
             icl_prof_scope ps(ctx, ICL_K_UPDATE, 3.0 * (double)(n - t - 1) * d, 4.0 * (double)(n - t - 1) * d + 4.0 * (double)(n - t - 1));
-            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
-                               w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
+            launch_update();
         } else {
-            hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(256), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
-                               w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->rescan, w->st, max_size);
+            launch_update();
         }
-        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(32), dim3(n > 2048 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
-                           w->rescan, &w->st->rescan_n, (int64_t)0, w->st, w->rowmin, w->rownn, w->slot_id, w->id_slot);
+        finish();
     };
     const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
     constexpr int GRAPH_STEPS = 64;
+    hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff,
+                       max_size, w->st); // merge 0 has no update in front of it
+    finish();
     if (prof_update || T < 2 * GRAPH_STEPS) {
         for (int64_t t = 0; t < T; ++t) enqueue_step(t, prof_update);
     } else {
