@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--max-size", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--embed-only", action="store_true", help="configs[3]: embed throughput without clustering")
+    ap.add_argument("--update", choices=["exact", "lw"], default="exact",
+                    help="exact: centroid recompute, cluster ids bit-identical to the reference (default); "
+                         "lw: MFMA distance tile + Lance-Williams rows (fast, not bit-identical)")
     args = ap.parse_args()
 
     import torch
@@ -91,39 +94,42 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        from imageclust_amd import distributed as D0
+
+        D0.init("nccl", rank, world, dev)  # nccl == RCCL on ROCm (xGMI inside the node)
 
     from imageclust_amd import _lib
+    from imageclust_amd import distributed as D
 
     ctx = _lib.Context(local_rank)
     ctx.load_synthetic(1)
     ctx.set_batch(args.batch)
     n_local = args.images_per_gpu
     n_total = n_local * world
-    D = _lib.HEAD_POOLED
+    DIM = _lib.HEAD_POOLED
 
     # synthetic inputs, generated on-device and resident in HBM before any timed region
     imgs = torch.empty(n_local * _lib.IMG_BYTES, dtype=torch.uint8, device=dev)
     ctx.synth_images_dev(20250217, rank * n_local, n_local, _lib.SYNTH_STRUCTURED, imgs.data_ptr())
     ctx.sync()
-    E_local = torch.empty((n_local, D), dtype=torch.float32, device=dev)
-    E_full = torch.empty((n_total, D), dtype=torch.float32, device=dev) if world > 1 else E_local
+    E_local = torch.empty((n_local, DIM), dtype=torch.float32, device=dev)
+    update = _lib.UPDATE_LW if args.update == "lw" else _lib.UPDATE_EXACT
     result = {}
 
     def step():
-        ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), D, _lib.PREC_BF16)  # returns with the stream idle
+        ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), DIM, _lib.PREC_BF16)  # returns with the stream idle
         st = ctx.last_stage_ms()
         result["embed_ms"] = st["embed_ms"]
+        E_full = E_local
         if world > 1:
             t0 = time.perf_counter()
-            dist.all_gather_into_tensor(E_full, E_local)
+            E_full = D.gather_embeddings(E_local, n_total, rank, world)  # ONE RCCL all-gather, shard order
             torch.cuda.synchronize()
             result["allgather_ms"] = (time.perf_counter() - t0) * 1e3
         if args.embed_only:
             return
         if rank == 0:
-            cid, mrank, nc = ctx.cluster_dev(E_full.data_ptr(), n_total, D, args.min_size, args.max_size)
+            cid, mrank, nc = ctx.cluster_dev(E_full.data_ptr(), n_total, DIM, args.min_size, args.max_size, update)
             st = ctx.last_stage_ms()
             result.update(dist_ms=st["dist_ms"], merge_ms=st["merge_ms"], n_clusters=nc, merges=len(ctx.last_merges()),
                           dropped=int((cid < 0).sum()))
@@ -146,10 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
 
     if rank == 0:
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -165,9 +168,11 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: %d synthetic 224x224x3 images per GPU (structured, seed 20250217), ResNet50-v1 bf16 "
-                                   "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d exact update on GPU0 -> cluster ids on host"
+                                   "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d on GPU0 -> cluster ids on host"
                                    % (n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
-                       "n_images_total": n_total, "embed_dim": D, "weights": "synthetic seed 1", "device": name},
+                       "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
+                       "ward_update": "exact (ids bit-identical to the reference)" if args.update == "exact"
+                       else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
             "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),

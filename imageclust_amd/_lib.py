@@ -278,6 +278,21 @@ class Context:
                                              rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
 
+    def distance_mfma(self, E):
+        """MFMA distance tile (K6): lower triangle (incl. zero diagonal) of 0.5*|e_i-e_j|^2, n x n fp32."""
+        E = np.ascontiguousarray(E, np.float32)
+        n, d = E.shape
+        dE, dD = self.malloc(max(E.nbytes, 16)), self.malloc(max(n * n * 4, 16))
+        try:
+            self.h2d(dE, E)
+            check(self.h, self.L.icl_distance_mfma_dev(self.h, _vp(dE), n, d, _vp(dD), n))
+            out = np.zeros((n, n), np.float32)
+            self.d2h(out, dD)
+        finally:
+            self.free(dE)
+            self.free(dD)
+        return np.tril(out)
+
     def last_merges(self):
         n = self.L.icl_last_merges(self.h, None, 0)
         out = np.zeros((max(n, 1), 2), np.int32)

@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstring>
 
+int icl_dist_mfma_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, float *d_out, const int64_t *d_rowoff, int64_t ld); // distance_mfma.hip
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct ward_state {
@@ -29,6 +31,7 @@ struct ward_state {
     int32_t target;    // merges to perform: N - k (clustering.go:220); further steps are no-ops
     int32_t nlive;     // live clusters occupy the dense slot range [0, nlive)
     int32_t mv_from, mv_to; // slot compaction of the current step: cluster in slot mv_from moves to mv_to (-1: none)
+    int32_t cur_sa, cur_sb;  // sizes of the merged pair (their asz entries are zeroed once they die)
     int32_t pre_row, pre_nn; // preselection: best pair among all rows except the newest cluster's (-1: none)
     float pre_val;
     int32_t pad;
@@ -61,6 +64,7 @@ struct icl_ward_ws {
     // hipGraph of GRAPH_STEPS merge steps (all step-varying state lives in device memory, so one capture replays)
     hipGraphExec_t graph_exec = nullptr;
     int graph_max_size = -1;
+    bool graph_lw = false;
 };
 
 void icl_ward_free(icl_ctx *ctx)
@@ -628,6 +632,8 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
         st->cur_a = a;
         st->cur_b = b;
         st->cur_c = c;
+        st->cur_sa = sa;
+        st->cur_sb = sb;
         st->cur_valid = 1;
         st->t = t + 1;
     }
@@ -776,6 +782,60 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
         key = o < key ? o : key;
     }
     if (lane == 0 && key != ~0ull) atomicMin(&st->ckey, key);
+}
+
+// update(t), FAST mode (ICL_UPDATE_LW): the new cluster's row by the Lance-Williams recurrence for Ward,
+//   d(c,x) = [ (sa+sx) d(a,x) + (sb+sx) d(b,x) - sx d(a,b) ] / (sa+sb+sx),
+// 12 bytes of reads per live cluster instead of 4*D.  Algebraically equal to clustering.go:84's centroid recompute
+// but NOT bit-equal (and it starts from the MFMA distance tile): cluster ids are reported, not asserted, against the
+// reference.  Same riders as the exact kernel: preselect(t+1) and the (unused here) compaction workgroup.
+__device__ __forceinline__ float tri_at(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int p, int q)
+{
+    return p > q ? Dtri[rowoff[p] + q] : Dtri[rowoff[q] + p];
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                                    const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                                    ward_state *__restrict__ st, int max_size, int64_t n,
+                                                                    float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int sh[2];
+    __shared__ unsigned long long skey[UPD_THREADS / 64];
+    if (blockIdx.x == gridDim.x - 1) {
+        ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        return;
+    }
+    if (st->done || !st->cur_valid) return;
+    const int nlive = st->nlive;
+    const int64_t slot = (int64_t)blockIdx.x * UPD_THREADS + threadIdx.x;
+    if ((int64_t)blockIdx.x * UPD_THREADS >= nlive) return;
+    const int a = st->cur_a, b = st->cur_b, c = st->cur_c, sa = st->cur_sa, sb = st->cur_sb;
+    const int x = slot < nlive ? slot_id[slot] : -1;
+    bool live = x >= 0 && x != c;
+    const int sx = live ? asz[x] : 0;
+    live = live && sx > 0;
+    const bool act = live && (sx + sa + sb <= max_size);
+    unsigned long long key = ~0ull;
+    if (act) {
+        const float dax = tri_at(Dtri, rowoff, a, x), dbx = tri_at(Dtri, rowoff, b, x), dab = tri_at(Dtri, rowoff, a, b);
+        float v = ((float)(sa + sx) * dax + (float)(sb + sx) * dbx - (float)sx * dab) / (float)(sa + sb + sx);
+        v = v > 0.0f ? v : 0.0f; // keeps the (bits, column) key order == value order
+        Dtri[rowoff[c] + x] = v;
+        if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(key, off, 64);
+        key = o < key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) skey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < UPD_THREADS / 64; ++wv) key = skey[wv] < key ? skey[wv] : key;
+        if (key != ~0ull) atomicMin(&st->ckey, key);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1036,7 +1096,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (icl_calc_optimal_clusters(n, min_size, max_size, &k) != ICL_OK)
         return icl_fail(ctx, ICL_ERR_CONSTRAINT, "cannot satisfy cluster size constraints with total items (%lld), minSize (%d), and maxSize (%d)",
                         (long long)n, min_size, max_size);
-    if (update != ICL_UPDATE_EXACT) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "update mode %d is not available in this build", update);
+    if (update != ICL_UPDATE_EXACT && update != ICL_UPDATE_LW) return icl_fail(ctx, ICL_ERR_ARG, "unknown update mode %d", update);
+    const bool lw = update == ICL_UPDATE_LW;
     if (n >= (1LL << 30)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "n too large");
     ctx->last_merges.clear();
     *n_clusters = 0;
@@ -1061,8 +1122,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         }
         ICL_HIP(ctx, hipGetLastError());
     }
-    // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle
-    ICL_TRY(launch_dist_exact(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0));
+    // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle: exact tile, or the MFMA tile in FAST mode
+    if (lw)
+        ICL_TRY(icl_dist_mfma_launch(ctx, d_E, n, d, w->Dtri, w->rowoff, 0));
+    else
+        ICL_TRY(launch_dist_exact(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0));
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
@@ -1083,7 +1147,13 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         hipLaunchKernelGGL(ward_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
                            w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->st);
     };
+    const unsigned lw_blocks = (unsigned)icl_ceil_div(w->S, UPD_THREADS) + 1;
     auto launch_update = [&]() {
+        if (lw) {
+            hipLaunchKernelGGL(ward_update_lw_kernel, dim3(lw_blocks), dim3(UPD_THREADS), 0, ctx->stream, w->slot_id, w->asz, w->rowoff, w->Dtri,
+                               w->st, max_size, n, w->rowmin, w->rownn);
+            return;
+        }
         hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(UPD_THREADS), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
                            w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
     };
@@ -1105,7 +1175,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (prof_update || T < 2 * GRAPH_STEPS) {
         for (int64_t t = 0; t < T; ++t) enqueue_step(t, prof_update);
     } else {
-        if (!w->graph_exec || w->graph_max_size != max_size) {
+        if (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != lw) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -1116,6 +1186,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
+            w->graph_lw = lw;
         }
         for (int64_t t = 0; t < T; t += GRAPH_STEPS) ICL_HIP(ctx, hipGraphLaunch(w->graph_exec, ctx->stream));
     }
