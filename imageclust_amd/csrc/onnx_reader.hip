@@ -1,0 +1,335 @@
+// onnx_reader.hip -- host-only: a dependency-free reader of ONNX ResNet50-v1 files (no protobuf, no onnx package).
+//
+// Replaces gocv.ReadNetFromONNX as used by LoadPretrainedModelONNX
+//   (/root/reference/internal/embeddings/embeddings.go:28-43; model path literal "resnet50-v1-7.onnx" at
+//    /root/reference/internal/workflow/workflow.go:49).
+// It walks the protobuf wire format of ModelProto.graph.{node,initializer}, follows the GRAPH (never a hard-coded
+// tensor naming scheme): Conv nodes in file order, the BatchNormalization that consumes each Conv's output, the Gemm
+// at the end; validates every Conv against the ResNet50-v1 topology (stride on the first 1x1 of a bottleneck) and
+// emits the "ICLW" blob of include/icl_model_format.h, which icl_model_load_blob then uploads.
+//
+// Field numbers (onnx.proto3): ModelProto.graph=7; GraphProto.node=1, .initializer=5; NodeProto.input=1, .output=2,
+// .op_type=4, .attribute=5; AttributeProto.name=1, .f=2, .i=3, .floats=7, .ints=8; TensorProto.dims=1, .data_type=2,
+// .float_data=4, .name=8, .raw_data=9.
+#include "icl_common.h"
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct span {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+};
+
+struct pb_reader {
+    const uint8_t *p, *end;
+    bool ok = true;
+    pb_reader(const uint8_t *b, size_t n) : p(b), end(b + n) {}
+    bool more() const { return ok && p < end; }
+    uint64_t varint()
+    {
+        uint64_t v = 0;
+        int shift = 0;
+        while (p < end && shift < 64) {
+            const uint8_t b = *p++;
+            v |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) return v;
+            shift += 7;
+        }
+        ok = false;
+        return 0;
+    }
+    // reads one field header; for length-delimited fields `s` receives the payload; for varint `v`; fixed32/64 in v
+    bool field(int &num, int &wt, uint64_t &v, span &s)
+    {
+        const uint64_t key = varint();
+        if (!ok) return false;
+        num = (int)(key >> 3);
+        wt = (int)(key & 7);
+        s = span();
+        v = 0;
+        switch (wt) {
+        case 0: v = varint(); break;
+        case 1:
+            if (end - p < 8) { ok = false; return false; }
+            memcpy(&v, p, 8);
+            p += 8;
+            break;
+        case 2: {
+            const uint64_t len = varint();
+            if (!ok || (uint64_t)(end - p) < len) { ok = false; return false; }
+            s.p = p;
+            s.n = (size_t)len;
+            p += len;
+            break;
+        }
+        case 5: {
+            if (end - p < 4) { ok = false; return false; }
+            uint32_t w;
+            memcpy(&w, p, 4);
+            v = w;
+            p += 4;
+            break;
+        }
+        default: ok = false; return false;
+        }
+        return ok;
+    }
+};
+
+struct onnx_tensor {
+    std::vector<int64_t> dims;
+    int dtype = 0;
+    span raw, fdata; // raw_data bytes, or packed float_data
+    std::vector<float> loose; // unpacked float_data entries (wire type 5), rare
+    int64_t count() const
+    {
+        int64_t c = 1;
+        for (auto d : dims) c *= d;
+        return c;
+    }
+    bool floats(std::vector<float> &out) const
+    {
+        const int64_t c = count();
+        out.resize((size_t)c);
+        if (dtype != 1) return false; // FLOAT
+        if (raw.n == (size_t)c * 4) { memcpy(out.data(), raw.p, raw.n); return true; }
+        if (fdata.n == (size_t)c * 4) { memcpy(out.data(), fdata.p, fdata.n); return true; }
+        if ((int64_t)loose.size() == c) { out = loose; return true; }
+        return false;
+    }
+};
+
+struct onnx_node {
+    std::string op;
+    std::vector<std::string> in, out;
+    std::map<std::string, std::vector<int64_t>> ints;
+    std::map<std::string, float> f;
+};
+
+static std::string str(const span &s) { return std::string((const char *)s.p, s.n); }
+
+static void parse_ints(const span &s, std::vector<int64_t> &out)
+{
+    pb_reader r(s.p, s.n);
+    while (r.more()) out.push_back((int64_t)r.varint());
+}
+
+static bool parse_tensor(const span &s, std::string &name, onnx_tensor &t)
+{
+    pb_reader r(s.p, s.n);
+    int num, wt;
+    uint64_t v;
+    span f;
+    while (r.more()) {
+        if (!r.field(num, wt, v, f)) return false;
+        if (num == 1) {
+            if (wt == 0) t.dims.push_back((int64_t)v);
+            else if (wt == 2) parse_ints(f, t.dims);
+        } else if (num == 2 && wt == 0) t.dtype = (int)v;
+        else if (num == 4) {
+            if (wt == 2) t.fdata = f;
+            else if (wt == 5) { uint32_t w = (uint32_t)v; float x; memcpy(&x, &w, 4); t.loose.push_back(x); }
+        } else if (num == 8 && wt == 2) name = str(f);
+        else if (num == 9 && wt == 2) t.raw = f;
+    }
+    return r.ok;
+}
+
+static bool parse_attr(const span &s, onnx_node &n)
+{
+    pb_reader r(s.p, s.n);
+    int num, wt;
+    uint64_t v;
+    span f;
+    std::string name;
+    std::vector<int64_t> ints;
+    bool has_i = false, has_f = false;
+    int64_t iv = 0;
+    float fv = 0;
+    while (r.more()) {
+        if (!r.field(num, wt, v, f)) return false;
+        if (num == 1 && wt == 2) name = str(f);
+        else if (num == 2 && wt == 5) { uint32_t w = (uint32_t)v; memcpy(&fv, &w, 4); has_f = true; }
+        else if (num == 3 && wt == 0) { iv = (int64_t)v; has_i = true; }
+        else if (num == 8) {
+            if (wt == 0) ints.push_back((int64_t)v);
+            else if (wt == 2) parse_ints(f, ints);
+        }
+    }
+    if (has_i) ints.push_back(iv);
+    if (!ints.empty()) n.ints[name] = ints;
+    if (has_f) n.f[name] = fv;
+    return r.ok;
+}
+
+static bool parse_node(const span &s, onnx_node &n)
+{
+    pb_reader r(s.p, s.n);
+    int num, wt;
+    uint64_t v;
+    span f;
+    while (r.more()) {
+        if (!r.field(num, wt, v, f)) return false;
+        if (wt != 2) continue;
+        if (num == 1) n.in.push_back(str(f));
+        else if (num == 2) n.out.push_back(str(f));
+        else if (num == 4) n.op = str(f);
+        else if (num == 5 && !parse_attr(f, n)) return false;
+    }
+    return r.ok;
+}
+
+static int resnet50_topology_onnx(icl_conv_rec *out)
+{
+    static const int nblocks[4] = {3, 4, 6, 3};
+    int n = 0;
+    out[n++] = icl_conv_rec{3, 64, 7, 2, 3, 224, 112, 0, 0, 0};
+    int h = 56, cin = 64;
+    for (int s = 0; s < 4; ++s) {
+        const int cout = 256 << s, mid = cout / 4;
+        for (int b = 0; b < nblocks[s]; ++b) {
+            const int stride = (b == 0 && s > 0) ? 2 : 1, ho = h / stride;
+            out[n++] = icl_conv_rec{cin, mid, 1, stride, 0, h, ho, 1, s + 1, b};
+            out[n++] = icl_conv_rec{mid, mid, 3, 1, 1, ho, ho, 2, s + 1, b};
+            out[n++] = icl_conv_rec{mid, cout, 1, 1, 0, ho, ho, 3, s + 1, b};
+            if (b == 0) out[n++] = icl_conv_rec{cin, cout, 1, stride, 0, h, ho, 4, s + 1, b};
+            cin = cout;
+            h = ho;
+        }
+    }
+    return n;
+}
+
+} // namespace
+
+// Parses an ONNX file into an ICLW blob.  Returns ICL_OK or ICL_ERR_IO with a message in ctx.
+int icl_onnx_to_blob(icl_ctx *ctx, const char *path, std::vector<char> &blob)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s", path); // embeddings.go:32
+    fseek(fp, 0, SEEK_END);
+    const long fsz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<uint8_t> file((size_t)std::max<long>(fsz, 0));
+    const bool rd = fsz > 0 && fread(file.data(), 1, file.size(), fp) == file.size();
+    fclose(fp);
+    if (!rd) return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s (empty or unreadable)", path);
+
+    // ModelProto -> graph
+    span graph;
+    {
+        pb_reader r(file.data(), file.size());
+        int num, wt;
+        uint64_t v;
+        span f;
+        while (r.more()) {
+            if (!r.field(num, wt, v, f)) break;
+            if (num == 7 && wt == 2) graph = f;
+        }
+        if (!r.ok || !graph.p) return icl_fail(ctx, ICL_ERR_IO, "%s: not an ONNX ModelProto (no graph)", path);
+    }
+    std::map<std::string, onnx_tensor> init;
+    std::vector<onnx_node> nodes;
+    {
+        pb_reader r(graph.p, graph.n);
+        int num, wt;
+        uint64_t v;
+        span f;
+        while (r.more()) {
+            if (!r.field(num, wt, v, f)) break;
+            if (wt != 2) continue;
+            if (num == 1) {
+                onnx_node n;
+                if (!parse_node(f, n)) return icl_fail(ctx, ICL_ERR_IO, "%s: malformed NodeProto", path);
+                nodes.push_back(std::move(n));
+            } else if (num == 5) {
+                std::string name;
+                onnx_tensor t;
+                if (!parse_tensor(f, name, t)) return icl_fail(ctx, ICL_ERR_IO, "%s: malformed TensorProto", path);
+                init[name] = std::move(t);
+            }
+        }
+        if (!r.ok) return icl_fail(ctx, ICL_ERR_IO, "%s: malformed GraphProto", path);
+    }
+    // consumer lookup: tensor name -> BatchNormalization node that reads it
+    std::map<std::string, const onnx_node *> bn_of;
+    const onnx_node *gemm = nullptr;
+    std::vector<const onnx_node *> convs;
+    for (const auto &n : nodes) {
+        if (n.op == "BatchNormalization" && n.in.size() >= 5) bn_of[n.in[0]] = &n;
+        else if (n.op == "Conv") convs.push_back(&n);
+        else if (n.op == "Gemm") gemm = &n;
+    }
+    icl_conv_rec topo[ICL_RESNET50_NCONV];
+    const int nconv = resnet50_topology_onnx(topo);
+    if ((int)convs.size() != nconv || !gemm)
+        return icl_fail(ctx, ICL_ERR_IO, "%s: expected a ResNet50-v1 graph (53 Conv + 1 Gemm), found %zu Conv%s", path, convs.size(), gemm ? "" : ", no Gemm");
+
+    icl_blob_header h;
+    memset(&h, 0, sizeof h);
+    h.magic = ICL_BLOB_MAGIC;
+    h.version = ICL_BLOB_VERSION;
+    h.n_conv = ICL_RESNET50_NCONV;
+    h.bn_eps = -1.0f;
+    std::vector<float> payload, tmp;
+    auto need = [&](const std::string &name, std::vector<int64_t> dims, const char *what, int idx) -> int {
+        auto it = init.find(name);
+        if (it == init.end()) return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d: initializer '%s' (%s) not found", path, idx, name.c_str(), what);
+        if (it->second.dims != dims || !it->second.floats(tmp))
+            return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d: initializer '%s' (%s) has the wrong shape or dtype", path, idx, name.c_str(), what);
+        payload.insert(payload.end(), tmp.begin(), tmp.end());
+        return ICL_OK;
+    };
+    for (int i = 0; i < nconv; ++i) {
+        const onnx_node &c = *convs[i];
+        const icl_conv_rec &t = topo[i];
+        if (c.in.size() < 2 || c.out.empty()) return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d has no weight input", path, i);
+        auto geti = [&](const char *k, size_t j, int64_t dflt) {
+            auto it = c.ints.find(k);
+            return (it == c.ints.end() || it->second.size() <= j) ? dflt : it->second[j];
+        };
+        const auto wit = init.find(c.in[1]);
+        if (wit == init.end() || wit->second.dims.size() != 4) return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d: weight initializer missing", path, i);
+        const auto &wd = wit->second.dims;
+        const int64_t k = wd[2];
+        if (wd[0] != t.cout || wd[1] != t.cin || wd[2] != t.k || wd[3] != t.k || geti("strides", 0, 1) != t.stride || geti("pads", 0, 0) != t.pad ||
+            geti("group", 0, 1) != 1 || geti("dilations", 0, 1) != 1 || geti("kernel_shape", 0, k) != t.k)
+            return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d is %lldx%lld k%lld s%lld p%lld, ResNet50-v1 expects %dx%d k%d s%d p%d", path, i,
+                            (long long)wd[1], (long long)wd[0], (long long)wd[2], (long long)geti("strides", 0, 1), (long long)geti("pads", 0, 0), t.cin,
+                            t.cout, t.k, t.stride, t.pad);
+        ICL_TRY(need(c.in[1], {t.cout, t.cin, t.k, t.k}, "W", i));
+        h.has_bias[i] = c.in.size() >= 3 && !c.in[2].empty();
+        if (h.has_bias[i]) ICL_TRY(need(c.in[2], {t.cout}, "B", i));
+        const auto bit = bn_of.find(c.out[0]);
+        if (bit == bn_of.end()) return icl_fail(ctx, ICL_ERR_IO, "%s: conv %d is not followed by BatchNormalization", path, i);
+        const onnx_node &bn = *bit->second;
+        const float eps = bn.f.count("epsilon") ? bn.f.at("epsilon") : 1e-5f;
+        if (h.bn_eps < 0) h.bn_eps = eps;
+        else if (h.bn_eps != eps) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "%s: BatchNormalization layers use different epsilons", path);
+        static const char *names[4] = {"scale", "B", "mean", "var"};
+        for (int q = 0; q < 4; ++q) ICL_TRY(need(bn.in[1 + q], {t.cout}, names[q], i));
+    }
+    // dense0: Gemm(x, W, b) with transB = 1 (W is [1000][2048]) or 0 (W is [2048][1000])
+    {
+        if (gemm->in.size() < 3) return icl_fail(ctx, ICL_ERR_IO, "%s: Gemm needs W and b", path);
+        const auto wit = init.find(gemm->in[1]);
+        if (wit == init.end() || !wit->second.floats(tmp)) return icl_fail(ctx, ICL_ERR_IO, "%s: Gemm weight missing", path);
+        const bool transB = gemm->ints.count("transB") && gemm->ints.at("transB")[0] == 1;
+        const std::vector<int64_t> want = transB ? std::vector<int64_t>{ICL_FC_OUT, ICL_FEAT_DIM} : std::vector<int64_t>{ICL_FEAT_DIM, ICL_FC_OUT};
+        if (wit->second.dims != want) return icl_fail(ctx, ICL_ERR_IO, "%s: Gemm weight has the wrong shape", path);
+        if (transB) payload.insert(payload.end(), tmp.begin(), tmp.end());
+        else
+            for (int o = 0; o < ICL_FC_OUT; ++o)
+                for (int i = 0; i < ICL_FEAT_DIM; ++i) payload.push_back(tmp[(size_t)i * ICL_FC_OUT + o]);
+        ICL_TRY(need(gemm->in[2], {ICL_FC_OUT}, "fc bias", 53));
+    }
+    blob.resize(sizeof h + payload.size() * 4);
+    memcpy(blob.data(), &h, sizeof h);
+    memcpy(blob.data() + sizeof h, payload.data(), payload.size() * 4);
+    return ICL_OK;
+}

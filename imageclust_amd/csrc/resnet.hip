@@ -621,14 +621,15 @@ extern "C" int icl_model_load_synthetic(icl_ctx *ctx, uint64_t seed)
     return icl_model_load_blob(ctx, blob.data(), nb);
 }
 
+int icl_onnx_to_blob(icl_ctx *ctx, const char *path, std::vector<char> &blob); // onnx_reader.hip
+
 extern "C" int icl_model_load_onnx(icl_ctx *ctx, const char *path)
 {
-    // LoadPretrainedModelONNX (embeddings.go:28-43).  The ONNX initializer reader is SURVEY.md 8f-1 ("next").
+    // LoadPretrainedModelONNX (embeddings.go:28-43): read the graph's initializers, validate the topology, upload.
     if (!ctx || !path) return icl_fail(ctx, ICL_ERR_ARG, "icl_model_load_onnx: bad argument");
-    FILE *f = fopen(path, "rb");
-    if (!f) return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s", path); // embeddings.go:32
-    fclose(f);
-    return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "ONNX initializer reader not built yet (SURVEY.md 8f-1); convert the model to an ICLW blob");
+    std::vector<char> blob;
+    ICL_TRY(icl_onnx_to_blob(ctx, path, blob));
+    return icl_model_load_blob(ctx, blob.data(), (int64_t)blob.size());
 }
 
 // ------------------------------------------------------------------------------------------------------------
