@@ -162,6 +162,15 @@ def main():
         avg_us = c128["ms"] * 1e3 / max(c128["launches"], 1)
         achieved = c128["flops"] / max(c128["ms"], 1e-9) / 1e9  # TFLOP/s
         name, ncu, hbm = ctx.device_info()
+        # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
+        # two separate rocprofv3 --pmc passes of `bench.py --embed-only`); committed under profiles/ because bench.py
+        # itself cannot run under the profiler.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json")) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"], 0)
+        except Exception:
+            pass
         out = {
             "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,7 +185,7 @@ def main():
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
             "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
                          "algorithmic_flops_per_launch": round(c128["flops"] / max(c128["launches"], 1), 0),
                          "all_conv_achieved": round((c128["flops"] + c64["flops"]) / max(c128["ms"] + c64["ms"], 1e-9) / 1e9, 2),

@@ -1,0 +1,72 @@
+"""End-to-end parity of the whole hot path at BASELINE.json configs[0] scale (64 images -> ResNet50 embed -> Ward
+min=3,max=6 => k=16, the constants hard-coded at internal/handlers/handlers.go:111), and the concurrency contract of
+the boundary (GetImageEmbedding is called from one goroutine per image: internal/workflow/workflow.go:156-175)."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from imageclust_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    c = L.Context(0)
+    c.load_synthetic(1)
+    yield c
+    c.close()
+
+
+def test_config0_64_images_embed_then_cluster(ctx, L):
+    from imageclust_amd import clustering as CL
+
+    imgs = L.synth_images(20250217, 0, 64, L.SYNTH_STRUCTURED)
+    E = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32)
+    blob = L.synthetic_blob(1)
+    for i in (0, 31, 63):  # the oracle's fp32 forward takes ~1 s per image: check three of the 64
+        ref, _ = O.resnet50_forward(blob, imgs[i])
+        assert np.abs(E[i] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    ids = ["img_%d" % i for i in range(64)]  # workflow.go:140
+    got, ok = CL.PerformClusteringWithConstraints(E, ids, 3, 6, ctx=ctx)
+    r = O.cluster(E, 3, 6)
+    assert ok and r["ok"] and O.calc_optimal_clusters(64, 3, 6) == (16, None)
+    assert got == O.clusters_as_map(r["cluster_id"], r["member_rank"], ids)  # same map, same member order
+    # bf16 throughput path: same shape of result, sizes within constraints
+    Eb = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_BF16)
+    gb, ok = CL.PerformClusteringWithConstraints(Eb, ids, 3, 6, ctx=ctx)
+    assert ok and all(3 <= len(v) <= 6 for v in gb.values())
+    rb = O.cluster(Eb, 3, 6)
+    assert gb == O.clusters_as_map(rb["cluster_id"], rb["member_rank"], ids)  # ids bit-identical on the SAME inputs
+
+
+def test_concurrent_callers_share_one_context(ctx, L):
+    imgs = L.synth_images(20250217, 100, 12, L.SYNTH_STRUCTURED)
+    want = ctx.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_FP32)
+    out = [None] * 12
+    errs = []
+
+    def worker(i):
+        try:
+            out[i] = ctx.embed_u8(imgs[i:i + 1], L.HEAD_DENSE0, L.PREC_FP32)[0]
+            if i % 3 == 0:  # interleave clustering calls on the same context
+                ctx.cluster(np.random.default_rng(i).standard_normal((40, 8)).astype(np.float32), 2, 5)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for i in range(12):
+        assert np.array_equal(out[i], want[i])
