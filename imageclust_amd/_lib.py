@@ -46,6 +46,8 @@ SYMBOLS = [
     ("icl_embed_u8_dev", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_embed_file", _int, [_vp, C.c_char_p, _int, _vp]),
     ("icl_preprocess_u8", _int, [_vp, _vp]),
+    ("icl_decode_image_file", _int, [C.c_char_p, _vp, _i64, _pi32, _pi32]),
+    ("icl_load_image_224", _int, [C.c_char_p, _vp]),
     ("icl_set_batch", _int, [_vp, _int]),
     ("icl_conv2d_fused", _int, [_vp, _int, _vp, _int, _int, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _int, _vp]),
     ("icl_calc_optimal_clusters", _int, [_i64, _i64, _i64, _pi64]),
@@ -304,6 +306,28 @@ def calc_optimal_clusters(total, min_size, max_size):
     k = _i64()
     rc = load().icl_calc_optimal_clusters(total, min_size, max_size, C.byref(k))
     return (k.value, None) if rc == ICL_OK else (0, rc)
+
+
+def decode_image_file(path):
+    """IMRead (embeddings.go:50) for baseline JPEG / binary PPM -> h x w x 3 u8 RGB."""
+    L = load()
+    w, h = _i32(), _i32()
+    rc = L.icl_decode_image_file(os.fsencode(path), None, 0, C.byref(w), C.byref(h))
+    if rc:
+        raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = L.icl_decode_image_file(os.fsencode(path), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h))
+    if rc:
+        raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
+    return out
+
+
+def load_image_224(path):
+    out = np.empty((224, 224, 3), np.uint8)
+    rc = load().icl_load_image_224(os.fsencode(path), out.ctypes.data)
+    if rc:
+        raise ICLError(rc, (load().icl_last_error(None) or b"").decode())
+    return out
 
 
 def synth_images(seed, first, n, mode=SYNTH_NOISE):

@@ -1,0 +1,459 @@
+// jpeg_decode.hip -- host-only baseline JPEG decoder for the image-ingest step of the hot path.
+//
+// Replaces gocv.IMRead(imagePath, IMReadColor) in PreprocessImage
+//   (/root/reference/internal/embeddings/embeddings.go:50), i.e. OpenCV imgcodecs -> libjpeg(-turbo) with its default
+// settings: integer "islow" IDCT, "fancy" (triangle) chroma upsampling and the fixed-point YCbCr->RGB tables.  Those
+// three algorithms are public (IJG libjpeg: jidctint.c, jdsample.c, jdcolor.c) and are restated here so that decoded
+// pixels are bit-identical to libjpeg-turbo's (checked against Pillow's bundled libjpeg-turbo in
+// tests/test_jpeg_decode.py).  Supported: 8-bit baseline / extended sequential Huffman (SOF0, SOF1), 1 or 3
+// components, 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals, JFIF / Adobe-transform markers.
+// Progressive (SOF2), arithmetic coding, 12-bit and CMYK return ICL_ERR_UNSUPPORTED.
+#include "icl_common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct huff_table {
+    bool present = false;
+    uint8_t bits[17] = {0};
+    uint8_t vals[256] = {0};
+    int mincode[17], maxcode[18], valptr[17];
+    uint16_t fast[512]; // 9-bit lookahead: (length << 8) | symbol, 0 = not resolvable in 9 bits
+    void build()
+    {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valptr[l] = k;
+            mincode[l] = code;
+            code += bits[l];
+            k += bits[l];
+            maxcode[l] = bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        memset(fast, 0, sizeof fast);
+        code = 0;
+        k = 0;
+        for (int l = 1; l <= 9; ++l) {
+            for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
+                const int lo = code << (9 - l), hi = lo + (1 << (9 - l));
+                for (int c = lo; c < hi; ++c) fast[c] = (uint16_t)((l << 8) | vals[k]);
+            }
+            code <<= 1;
+        }
+    }
+};
+
+struct component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int wblocks = 0, hblocks = 0; // padded to whole MCUs
+    int dw = 0, dh = 0;           // downsampled_width / _height (real samples)
+    int pred = 0;
+    std::vector<uint8_t> plane;   // wblocks*8 x hblocks*8
+};
+
+struct bit_reader {
+    const uint8_t *p, *end;
+    uint32_t acc = 0;
+    int nbits = 0;
+    bool hit_marker = false;
+    void fill()
+    {
+        while (nbits <= 24) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    if (p < end && *p == 0x00) ++p;                 // stuffed zero
+                    else { hit_marker = true; --p; b = 0; }         // a real marker: feed zeros from here on
+                }
+            }
+            acc |= (uint32_t)b << (24 - nbits);
+            nbits += 8;
+        }
+    }
+    int peek(int n) { fill(); return (int)(acc >> (32 - n)); }
+    void skip(int n) { acc <<= n; nbits -= n; }
+    int get(int n)
+    {
+        if (n == 0) return 0;
+        const int v = peek(n);
+        skip(n);
+        return v;
+    }
+    void reset() { acc = 0; nbits = 0; hit_marker = false; }
+};
+
+inline int huff_decode(bit_reader &br, const huff_table &t)
+{
+    const int look = br.peek(9);
+    const uint16_t f = t.fast[look];
+    if (f) {
+        br.skip(f >> 8);
+        return f & 0xff;
+    }
+    int code = br.peek(16), l = 10;
+    for (; l <= 16; ++l) {
+        const int c = code >> (16 - l);
+        if (t.maxcode[l] >= 0 && c <= t.maxcode[l] && c >= t.mincode[l]) {
+            br.skip(l);
+            return t.vals[t.valptr[l] + c - t.mincode[l]];
+        }
+    }
+    return -1;
+}
+
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// IJG jidctint.c jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2.  coef is dequantized, natural order.
+void idct_islow(const int *coef, uint8_t *out, int stride)
+{
+    constexpr int CB = 13, P1 = 2;
+    constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+                  F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    auto descale = [](long x, int n) { return (int)((x + (1L << (n - 1))) >> n); };
+    int ws[64];
+    for (int c = 0; c < 8; ++c) {
+        const int *in = coef + c;
+        int *w = ws + c;
+        if (!(in[8] | in[16] | in[24] | in[32] | in[40] | in[48] | in[56])) {
+            const int dc = in[0] * (1 << P1);
+            for (int r = 0; r < 8; ++r) w[8 * r] = dc;
+            continue;
+        }
+        long z2 = in[16], z3 = in[48];
+        long z1 = (z2 + z3) * F0_541;
+        long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+        z2 = in[0];
+        z3 = in[32];
+        long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = in[56];
+        tmp1 = in[40];
+        tmp2 = in[24];
+        tmp3 = in[8];
+        z1 = tmp0 + tmp3;
+        z2 = tmp1 + tmp2;
+        z3 = tmp0 + tmp2;
+        long z4 = tmp1 + tmp3;
+        const long z5 = (z3 + z4) * F1_175;
+        tmp0 *= F0_298;
+        tmp1 *= F2_053;
+        tmp2 *= F3_072;
+        tmp3 *= F1_501;
+        z1 *= -F0_899;
+        z2 *= -F2_562;
+        z3 *= -F1_961;
+        z4 *= -F0_390;
+        z3 += z5;
+        z4 += z5;
+        tmp0 += z1 + z3;
+        tmp1 += z2 + z4;
+        tmp2 += z2 + z3;
+        tmp3 += z1 + z4;
+        w[0] = descale(tmp10 + tmp3, CB - P1);
+        w[56] = descale(tmp10 - tmp3, CB - P1);
+        w[8] = descale(tmp11 + tmp2, CB - P1);
+        w[48] = descale(tmp11 - tmp2, CB - P1);
+        w[16] = descale(tmp12 + tmp1, CB - P1);
+        w[40] = descale(tmp12 - tmp1, CB - P1);
+        w[24] = descale(tmp13 + tmp0, CB - P1);
+        w[32] = descale(tmp13 - tmp0, CB - P1);
+    }
+    for (int r = 0; r < 8; ++r) {
+        const int *w = ws + 8 * r;
+        uint8_t *o = out + (size_t)r * stride;
+        long z2 = w[2], z3 = w[6];
+        long z1 = (z2 + z3) * F0_541;
+        long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+        long tmp0 = ((long)w[0] + w[4]) * (1L << CB), tmp1 = ((long)w[0] - w[4]) * (1L << CB);
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w[7];
+        tmp1 = w[5];
+        tmp2 = w[3];
+        tmp3 = w[1];
+        z1 = tmp0 + tmp3;
+        z2 = tmp1 + tmp2;
+        z3 = tmp0 + tmp2;
+        long z4 = tmp1 + tmp3;
+        const long z5 = (z3 + z4) * F1_175;
+        tmp0 *= F0_298;
+        tmp1 *= F2_053;
+        tmp2 *= F3_072;
+        tmp3 *= F1_501;
+        z1 *= -F0_899;
+        z2 *= -F2_562;
+        z3 *= -F1_961;
+        z4 *= -F0_390;
+        z3 += z5;
+        z4 += z5;
+        tmp0 += z1 + z3;
+        tmp1 += z2 + z4;
+        tmp2 += z2 + z3;
+        tmp3 += z1 + z4;
+        constexpr int S = CB + P1 + 3;
+        // range_limit[(x) & RANGE_MASK] of libjpeg == clamp(x + 128) for every value a legal stream can produce
+        o[0] = clamp8(descale(tmp10 + tmp3, S) + 128);
+        o[7] = clamp8(descale(tmp10 - tmp3, S) + 128);
+        o[1] = clamp8(descale(tmp11 + tmp2, S) + 128);
+        o[6] = clamp8(descale(tmp11 - tmp2, S) + 128);
+        o[2] = clamp8(descale(tmp12 + tmp1, S) + 128);
+        o[5] = clamp8(descale(tmp12 - tmp1, S) + 128);
+        o[3] = clamp8(descale(tmp13 + tmp0, S) + 128);
+        o[4] = clamp8(descale(tmp13 - tmp0, S) + 128);
+    }
+}
+
+} // namespace
+
+// Decodes a JPEG file held in memory to interleaved RGB.  rgb is resized to w*h*3.
+int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H)
+{
+    auto fail = [&](int code, const char *what) { return icl_fail(ctx, code, "failed to read image: %s. %s", path, what); };
+    if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(ICL_ERR_IO, "Not a JPEG stream");
+    uint16_t qt[4][64];
+    bool qt_ok[4] = {false, false, false, false};
+    huff_table dc[4], ac[4];
+    component comp[3];
+    int ncomp = 0, restart = 0, hmax = 1, vmax = 1;
+    bool have_sof = false, adobe = false, decoded = false;
+    int adobe_transform = -1;
+    size_t pos = 2;
+    W = H = 0;
+    while (pos + 4 <= len && !decoded) {
+        if (data[pos] != 0xFF) { ++pos; continue; }
+        const int m = data[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) break;
+        if (pos + 2 > len) break;
+        const size_t seglen = ((size_t)data[pos] << 8) | data[pos + 1];
+        if (seglen < 2 || pos + seglen > len) return fail(ICL_ERR_IO, "The image file might be corrupt or unreadable");
+        const uint8_t *s = data + pos + 2;
+        const size_t sl = seglen - 2;
+        if (m == 0xDB) { // DQT
+            size_t i = 0;
+            while (i < sl) {
+                const int pq = s[i] >> 4, tq = s[i] & 15;
+                ++i;
+                if (tq > 3 || i + (pq ? 128 : 64) > sl) return fail(ICL_ERR_IO, "Bad quantization table");
+                for (int k = 0; k < 64; ++k) {
+                    qt[tq][zigzag[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
+                    i += pq ? 2 : 1;
+                }
+                qt_ok[tq] = true;
+            }
+        } else if (m == 0xC4) { // DHT
+            size_t i = 0;
+            while (i + 17 <= sl) {
+                const int tc = s[i] >> 4, th = s[i] & 15;
+                if (tc > 1 || th > 3) return fail(ICL_ERR_IO, "Bad Huffman table");
+                huff_table &t = tc ? ac[th] : dc[th];
+                int total = 0;
+                t.bits[0] = 0;
+                for (int l = 1; l <= 16; ++l) { t.bits[l] = s[i + l]; total += t.bits[l]; }
+                i += 17;
+                if (total > 256 || i + total > sl) return fail(ICL_ERR_IO, "Bad Huffman table");
+                memcpy(t.vals, s + i, (size_t)total);
+                i += total;
+                t.present = true;
+                t.build();
+            }
+        } else if (m == 0xC0 || m == 0xC1) { // SOF0 / SOF1
+            if (sl < 6 || s[0] != 8) return fail(ICL_ERR_UNSUPPORTED, "Only 8-bit JPEG is decoded");
+            H = (s[1] << 8) | s[2];
+            W = (s[3] << 8) | s[4];
+            ncomp = s[5];
+            if ((ncomp != 1 && ncomp != 3) || sl < (size_t)(6 + 3 * ncomp) || W <= 0 || H <= 0 || W > 32768 || H > 32768)
+                return fail(ICL_ERR_UNSUPPORTED, "Only 1- or 3-component JPEG is decoded");
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].id = s[6 + 3 * c];
+                comp[c].h = s[7 + 3 * c] >> 4;
+                comp[c].v = s[7 + 3 * c] & 15;
+                comp[c].tq = s[8 + 3 * c];
+                hmax = std::max(hmax, comp[c].h);
+                vmax = std::max(vmax, comp[c].v);
+            }
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            return fail(ICL_ERR_UNSUPPORTED, "Progressive / lossless / arithmetic JPEG is not decoded by this build (baseline only)");
+        } else if (m == 0xDD) {
+            if (sl >= 2) restart = (s[0] << 8) | s[1];
+        } else if (m == 0xEE) {
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
+        } else if (m == 0xDA) { // SOS: the whole (single) scan of a baseline file
+            if (!have_sof) return fail(ICL_ERR_IO, "Scan before frame header");
+            const int ns = s[0];
+            if (ns != ncomp || sl < (size_t)(1 + 2 * ns + 3)) return fail(ICL_ERR_UNSUPPORTED, "Non-interleaved multi-scan JPEG is not decoded");
+            for (int i = 0; i < ns; ++i) {
+                int ci = -1;
+                for (int c = 0; c < ncomp; ++c)
+                    if (comp[c].id == s[1 + 2 * i]) ci = c;
+                if (ci < 0) return fail(ICL_ERR_IO, "Bad scan component");
+                comp[ci].td = s[2 + 2 * i] >> 4;
+                comp[ci].ta = s[2 + 2 * i] & 15;
+            }
+            if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }
+            if (ncomp == 3) {
+                const bool ok = comp[1].h == 1 && comp[1].v == 1 && comp[2].h == 1 && comp[2].v == 1 && (comp[0].h == 1 || comp[0].h == 2) &&
+                                (comp[0].v == 1 || comp[0].v == 2) && !(comp[0].h == 1 && comp[0].v == 2);
+                if (!ok) return fail(ICL_ERR_UNSUPPORTED, "Only 4:4:4, 4:2:2 and 4:2:0 chroma sampling is decoded");
+            }
+            const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            for (int c = 0; c < ncomp; ++c) {
+                component &k = comp[c];
+                if (k.tq > 3 || !qt_ok[k.tq] || k.td > 3 || k.ta > 3 || !dc[k.td].present || !ac[k.ta].present) return fail(ICL_ERR_IO, "Missing table");
+                k.wblocks = mcux * k.h;
+                k.hblocks = mcuy * k.v;
+                k.dw = (W * k.h + hmax - 1) / hmax;
+                k.dh = (H * k.v + vmax - 1) / vmax;
+                k.plane.assign((size_t)k.wblocks * 8 * k.hblocks * 8, 0);
+                k.pred = 0;
+            }
+            bit_reader br{data + pos + seglen, data + len};
+            int coef[64];
+            int rst_left = restart;
+            for (int my = 0; my < mcuy; ++my)
+                for (int mx = 0; mx < mcux; ++mx) {
+                    if (restart && rst_left == 0) {
+                        // byte-align, expect RSTn
+                        const uint8_t *q = br.p;
+                        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                        if (q + 1 >= br.end) return fail(ICL_ERR_IO, "Missing restart marker");
+                        br.p = q + 2;
+                        br.reset();
+                        for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                        rst_left = restart;
+                    }
+                    for (int c = 0; c < ncomp; ++c) {
+                        component &k = comp[c];
+                        for (int by = 0; by < k.v; ++by)
+                            for (int bx = 0; bx < k.h; ++bx) {
+                                memset(coef, 0, sizeof coef);
+                                int t = huff_decode(br, dc[k.td]);
+                                if (t < 0 || t > 15) return fail(ICL_ERR_IO, "Corrupt JPEG data");
+                                const int diff = t ? extend(br.get(t), t) : 0;
+                                k.pred += diff;
+                                coef[0] = k.pred * qt[k.tq][0];
+                                for (int i = 1; i < 64;) {
+                                    const int rs = huff_decode(br, ac[k.ta]);
+                                    if (rs < 0) return fail(ICL_ERR_IO, "Corrupt JPEG data");
+                                    const int r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) {
+                                        if (r == 15) { i += 16; continue; }
+                                        break;
+                                    }
+                                    i += r;
+                                    if (i > 63) return fail(ICL_ERR_IO, "Corrupt JPEG data");
+                                    coef[zigzag[i]] = extend(br.get(sz), sz) * qt[k.tq][zigzag[i]];
+                                    ++i;
+                                }
+                                const size_t stride = (size_t)k.wblocks * 8;
+                                idct_islow(coef, k.plane.data() + ((size_t)(my * k.v + by) * 8) * stride + (size_t)(mx * k.h + bx) * 8, (int)stride);
+                            }
+                    }
+                    if (restart) --rst_left;
+                }
+            decoded = true;
+        }
+        pos += seglen;
+    }
+    if (!decoded) return fail(ICL_ERR_IO, "The image file might be corrupt or unreadable");
+    rgb.assign((size_t)W * H * 3, 0);
+    if (ncomp == 1) {
+        const size_t stride = (size_t)comp[0].wblocks * 8;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const uint8_t g = comp[0].plane[y * stride + x];
+                uint8_t *o = &rgb[((size_t)y * W + x) * 3];
+                o[0] = o[1] = o[2] = g;
+            }
+        return ICL_OK;
+    }
+    // chroma upsampling (jdsample.c): h2v1 / h2v2 "fancy" triangle filters, or none
+    const int hs = comp[0].h, vs = comp[0].v;
+    std::vector<uint8_t> up[2];
+    for (int c = 1; c <= 2; ++c) {
+        const component &k = comp[c];
+        const size_t stride = (size_t)k.wblocks * 8;
+        std::vector<uint8_t> &o = up[c - 1];
+        o.assign((size_t)W * H, 0);
+        const int dw = k.dw, dh = k.dh;
+        auto in = [&](int r) -> const uint8_t * { return k.plane.data() + (size_t)std::min(std::max(r, 0), dh - 1) * stride; };
+        if (hs == 1 && vs == 1) {
+            for (int y = 0; y < H; ++y) memcpy(&o[(size_t)y * W], in(y), (size_t)W);
+        } else if (hs == 2 && vs == 1) {
+            std::vector<uint8_t> row((size_t)dw * 2 + 2);
+            for (int y = 0; y < H; ++y) {
+                const uint8_t *p = in(y);
+                if (dw == 1) { row[0] = row[1] = p[0]; }
+                else {
+                    row[0] = p[0];
+                    row[1] = (uint8_t)((p[0] * 3 + p[1] + 2) >> 2);
+                    for (int i = 1; i < dw - 1; ++i) {
+                        row[2 * i] = (uint8_t)((p[i] * 3 + p[i - 1] + 1) >> 2);
+                        row[2 * i + 1] = (uint8_t)((p[i] * 3 + p[i + 1] + 2) >> 2);
+                    }
+                    row[2 * (dw - 1)] = (uint8_t)((p[dw - 1] * 3 + p[dw - 2] + 1) >> 2);
+                    row[2 * (dw - 1) + 1] = p[dw - 1];
+                }
+                memcpy(&o[(size_t)y * W], row.data(), (size_t)W);
+            }
+        } else { // h2v2
+            std::vector<int> cs0((size_t)dw), cs1((size_t)dw);
+            std::vector<uint8_t> row((size_t)dw * 2 + 2);
+            for (int y = 0; y < H; ++y) {
+                const int r = y >> 1;
+                const uint8_t *p0 = in(r), *p1 = in((y & 1) ? r + 1 : r - 1); // nearer / further input row
+                int *cs = cs0.data();
+                for (int i = 0; i < dw; ++i) cs[i] = p0[i] * 3 + p1[i];
+                if (dw == 1) {
+                    row[0] = (uint8_t)((cs[0] * 4 + 8) >> 4);
+                    row[1] = (uint8_t)((cs[0] * 4 + 7) >> 4);
+                } else {
+                    row[0] = (uint8_t)((cs[0] * 4 + 8) >> 4);
+                    row[1] = (uint8_t)((cs[0] * 3 + cs[1] + 7) >> 4);
+                    for (int i = 1; i < dw - 1; ++i) {
+                        row[2 * i] = (uint8_t)((cs[i] * 3 + cs[i - 1] + 8) >> 4);
+                        row[2 * i + 1] = (uint8_t)((cs[i] * 3 + cs[i + 1] + 7) >> 4);
+                    }
+                    row[2 * (dw - 1)] = (uint8_t)((cs[dw - 1] * 3 + cs[dw - 2] + 8) >> 4);
+                    row[2 * (dw - 1) + 1] = (uint8_t)((cs[dw - 1] * 4 + 7) >> 4);
+                }
+                memcpy(&o[(size_t)y * W], row.data(), (size_t)W);
+            }
+        }
+    }
+    // colour conversion (jdcolor.c): fixed-point YCbCr -> RGB, or pass-through for Adobe transform 0
+    const bool is_rgb = (adobe && adobe_transform == 0) || (!adobe && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B');
+    int cr_r[256], cb_b[256], cr_g[256], cb_g[256];
+    for (int i = 0; i < 256; ++i) {
+        const int x = i - 128;
+        cr_r[i] = (int)((91881L * x + 32768) >> 16);   // FIX(1.40200)
+        cb_b[i] = (int)((116130L * x + 32768) >> 16);  // FIX(1.77200)
+        cr_g[i] = (int)(-46802L * x);                  // FIX(0.71414)
+        cb_g[i] = (int)(-22554L * x + 32768);          // FIX(0.34414)
+    }
+    const size_t ystride = (size_t)comp[0].wblocks * 8;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int Y = comp[0].plane[y * ystride + x], cb = up[0][(size_t)y * W + x], cr = up[1][(size_t)y * W + x];
+            uint8_t *o = &rgb[((size_t)y * W + x) * 3];
+            if (is_rgb) {
+                o[0] = (uint8_t)Y; o[1] = (uint8_t)cb; o[2] = (uint8_t)cr;
+            } else {
+                o[0] = clamp8(Y + cr_r[cr]);
+                o[1] = clamp8(Y + ((cb_g[cb] + cr_g[cr]) >> 16));
+                o[2] = clamp8(Y + cb_b[cb]);
+            }
+        }
+    return ICL_OK;
+}

@@ -988,7 +988,55 @@ static int read_ppm(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, i
         ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
     }
     fclose(f);
-    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only binary PPM (P6, maxval 255) is decoded by this build (JPEG: SURVEY.md 8f-2)", path);
+    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only baseline JPEG and binary PPM (P6, maxval 255) are decoded by this build", path);
+    return ICL_OK;
+}
+
+int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H); // jpeg_decode.hip
+
+// IMRead(IMReadColor) of embeddings.go:50 for the two formats this build decodes.
+static int read_image(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path); // embeddings.go:52
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, f);
+    if (got == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> file((size_t)std::max<long>(sz, 0));
+        const bool ok = sz > 0 && fread(file.data(), 1, file.size(), f) == file.size();
+        fclose(f);
+        if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path);
+        return icl_jpeg_decode(ctx, file.data(), file.size(), path, rgb, w, h);
+    }
+    fclose(f);
+    return read_ppm(ctx, path, rgb, w, h);
+}
+
+extern "C" int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h)
+{
+    if (!path || !w || !h) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: bad argument");
+    std::vector<uint8_t> px;
+    int iw = 0, ih = 0;
+    ICL_TRY(read_image(nullptr, path, px, iw, ih));
+    *w = iw;
+    *h = ih;
+    if (rgb) {
+        if (cap_bytes < (int64_t)px.size()) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: buffer too small");
+        memcpy(rgb, px.data(), px.size());
+    }
+    return ICL_OK;
+}
+
+extern "C" int icl_load_image_224(const char *path, uint8_t *out)
+{
+    if (!path || !out) return icl_fail(nullptr, ICL_ERR_ARG, "icl_load_image_224: bad argument");
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    ICL_TRY(read_image(nullptr, path, px, w, h));
+    resize_bilinear_u8(px.data(), w, h, out, ICL_IMG_W, ICL_IMG_H);
     return ICL_OK;
 }
 
@@ -997,7 +1045,7 @@ extern "C" int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *o
     if (!ctx || !path || !out) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_file: bad argument");
     std::vector<uint8_t> rgb, img((size_t)ICL_IMG_BYTES);
     int w = 0, h = 0;
-    ICL_TRY(read_ppm(ctx, path, rgb, w, h));
+    ICL_TRY(read_image(ctx, path, rgb, w, h));
     resize_bilinear_u8(rgb.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
     return icl_embed_u8(ctx, img.data(), 1, head, ICL_PREC_FP32, out);
 }

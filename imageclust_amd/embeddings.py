@@ -4,7 +4,6 @@ Same names and error behaviour as the Go package; gocv.Net / gocv.Mat become thi
 GenerateLabelVector / CombineEmbeddings / BuildLabelSet (embeddings.go:166-236) are Rekognition-side glue and are
 out of scope.  No CPU fallback: every forward pass runs in libimageclust_hip.so.
 """
-import os
 import threading
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -77,36 +76,13 @@ def LoadPretrainedModelONNX(modelPath: str, device: int = 0):
         return Net(None), "failed to load ResNet50 ONNX model from: %s (%s)" % (modelPath, e)
 
 
-def _read_ppm(path):
-    with open(path, "rb") as f:
-        data = f.read()
-    if data[:2] != b"P6":
-        raise ValueError("not a binary PPM")
-    toks, pos = [], 2
-    while len(toks) < 3:
-        while data[pos:pos + 1].isspace():
-            pos += 1
-        if data[pos:pos + 1] == b"#":
-            pos = data.index(b"\n", pos) + 1
-            continue
-        end = pos
-        while not data[end:end + 1].isspace():
-            end += 1
-        toks.append(int(data[pos:end]))
-        pos = end
-    w, h, mx = toks
-    return np.frombuffer(data, np.uint8, w * h * 3, pos + 1).reshape(h, w, 3), w, h
-
-
 def PreprocessImage(imagePath: str):
-    """embeddings.go:46-116 -> (Mat, err).  Only 224x224 binary PPM files are taken on this path; other sizes go
-    through icl_embed_file's OpenCV-compatible resize inside GetImageEmbedding."""
+    """embeddings.go:46-116 -> (Mat, err): IMRead (baseline JPEG / binary PPM, decoded bit-identically to libjpeg-turbo) ->
+    Resize 224x224 INTER_LINEAR -> RGB; Mat.Blob() gives the 1x3x224x224 fp32 blob scaled by 1/255."""
     try:
-        rgb, w, h = _read_ppm(imagePath)
-    except Exception:
-        return None, ("failed to read image: %s. The image file might be corrupt or unreadable" % imagePath)
-    if (w, h) != (224, 224):
-        return None, "invalid blob shape for image %s: expected (1, 3, 224, 224), got %s" % (imagePath, [1, 3, h, w])
+        rgb = _lib.load_image_224(imagePath)
+    except _lib.ICLError as e:
+        return None, str(e).split(": ", 1)[-1]
     return Mat(rgb), None
 
 

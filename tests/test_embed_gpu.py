@@ -162,4 +162,14 @@ def test_reference_style_api(ctx, L, tmp_path):
     q.write_bytes(b"P6\n300 260\n255\n" + big.tobytes())
     emb3, err = EM.GetImageEmbedding(app, str(q))
     assert err is None and np.isfinite(emb3).all()
+    # a JPEG goes through the same path: decode (libjpeg-turbo-exact) -> resize -> embed
+    from PIL import Image
+
+    j = tmp_path / "photo.jpg"
+    Image.fromarray(big).save(str(j), "JPEG", quality=90)
+    emb4, err = EM.GetImageEmbedding(app, str(j))
+    assert err is None
+    assert np.array_equal(emb4, ctx.embed_u8(L.load_image_224(str(j))[None], L.HEAD_DENSE0, L.PREC_FP32)[0])
+    mat, err = EM.PreprocessImage(str(j))
+    assert err is None and mat.rgb.shape == (224, 224, 3)
     net.Close()

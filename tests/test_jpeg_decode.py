@@ -1,0 +1,81 @@
+"""Image ingest (embeddings.go:50, gocv.IMRead -> libjpeg-turbo): the engine's baseline JPEG decoder must reproduce
+libjpeg-turbo's pixels bit for bit (islow IDCT, fancy upsampling, fixed-point YCbCr->RGB).  Pillow bundles
+libjpeg-turbo and is used here as the independent reference decoder.  Host-only code: runs without a GPU."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from imageclust_amd import _lib
+
+
+def picture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 17.0 + y / 31.0), 128 + 90 * np.cos(x / 11.0 - y / 23.0), (x * 255 // max(w - 1, 1) + y) % 256], -1)
+    return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+
+
+def roundtrip(tmp_path, im, **save_kw):
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", **save_kw)
+    p = tmp_path / "t.jpg"
+    p.write_bytes(buf.getvalue())
+    ref = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    return _lib.decode_image_file(str(p)), ref
+
+
+@pytest.mark.parametrize("size", [(64, 64), (224, 224), (37, 53), (300, 260), (17, 9), (8, 8), (1, 1), (481, 322)])
+@pytest.mark.parametrize("sub", [0, 1, 2])
+def test_matches_libjpeg_turbo(tmp_path, size, sub):
+    for q in (35, 90, 100):
+        got, ref = roundtrip(tmp_path, Image.fromarray(picture(*size, seed=q)), quality=q, subsampling=sub)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (size, sub, q)
+
+
+def test_grayscale_optimized_tables_and_restart_markers(tmp_path):
+    im = Image.fromarray(picture(150, 211, 1))
+    got, ref = roundtrip(tmp_path, im.convert("L"), quality=80)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=75, optimize=True, subsampling=2)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=75, subsampling=2, restart_marker_blocks=3)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=75, subsampling=1, restart_marker_rows=1)
+    assert np.array_equal(got, ref)
+
+
+def test_unsupported_and_corrupt_files(tmp_path):
+    im = Image.fromarray(picture(64, 64, 2))
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", progressive=True)
+    p = tmp_path / "prog.jpg"
+    p.write_bytes(buf.getvalue())
+    with pytest.raises(_lib.ICLError) as ei:
+        _lib.decode_image_file(str(p))
+    assert ei.value.code == _lib.ICL_ERR_UNSUPPORTED and "failed to read image" in str(ei.value)
+    buf = io.BytesIO()
+    im.save(buf, "JPEG")
+    q = tmp_path / "trunc.jpg"
+    q.write_bytes(buf.getvalue()[:200])
+    with pytest.raises(_lib.ICLError) as ei:
+        _lib.decode_image_file(str(q))
+    assert ei.value.code == _lib.ICL_ERR_IO
+    with pytest.raises(_lib.ICLError):
+        _lib.decode_image_file(str(tmp_path / "missing.jpg"))
+
+
+def test_load_image_224_identity_and_resize(tmp_path):
+    im = picture(224, 224, 3)
+    got, ref = roundtrip(tmp_path, Image.fromarray(im), quality=95, subsampling=0)
+    assert np.array_equal(_lib.load_image_224(str(tmp_path / "t.jpg")), ref)  # 224x224: cv::resize is the identity
+    big = picture(448, 448, 4)
+    (tmp_path / "b.ppm").write_bytes(b"P6\n448 448\n255\n" + big.tobytes())
+    out = _lib.load_image_224(str(tmp_path / "b.ppm"))
+    # INTER_LINEAR at an exact 2:1 ratio samples the centre of each 2x2 block: the (rounded) mean of its 4 pixels
+    box = big.reshape(224, 2, 224, 2, 3).astype(np.int32).sum((1, 3))
+    assert np.abs(out.astype(np.int32) - (box + 2) // 4).max() <= 1
+    const = np.full((50, 70, 3), 77, np.uint8)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n70 50\n255\n" + const.tobytes())
+    assert (_lib.load_image_224(str(tmp_path / "c.ppm")) == 77).all()
