@@ -667,56 +667,76 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
                                                                int max_size, int64_t n, float *__restrict__ rowmin,
                                                                int32_t *__restrict__ rownn_w)
 {
-    __shared__ float4 ring[2][UPD_SG][64]; // 48 KiB
+    extern __shared__ __attribute__((aligned(16))) float4 upd_lds[]; // [2][UPD_SG][64] p ring, then the new centroid image
+    float4 (*ring)[UPD_SG][64] = reinterpret_cast<float4 (*)[UPD_SG][64]>(upd_lds);
     if (blockIdx.x == gridDim.x - 2) { // preselect(t+1) rides along as one workgroup: it never touches row c / ckey
-        float *sv = reinterpret_cast<float *>(&ring[0][0][0]);
+        float *sv = reinterpret_cast<float *>(upd_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
         int *sh = si + 16;
         ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, max_size, st, sv, si, sh);
         return;
     }
-    if (st->done || !st->cur_valid) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: role and addresses stay scalar
-    if (blockIdx.x == gridDim.x - 1) { // compaction copy (disjoint from every column read below: mv_to is a free slot)
-        const int from = st->mv_from, to = st->mv_to;
-        if (to < 0) return;
-        const int dq = (d + 3) >> 2;
-        for (int g = threadIdx.x; g < dq; g += UPD_THREADS)
-            *reinterpret_cast<float4 *>(CT + ct4_off(g, S, to)) = *reinterpret_cast<const float4 *>(CT + ct4_off(g, S, from));
-        for (int k = threadIdx.x; k < d; k += UPD_THREADS) Crow[(int64_t)to * d + k] = Crow[(int64_t)from * d + k];
-        return;
-    }
-    const int nlive = st->nlive;
-    if ((int64_t)blockIdx.x * 64 >= nlive) return;
-    const int64_t slot = (int64_t)blockIdx.x * 64 + lane; // S is a multiple of 64
-    const int a = st->cur_a, b = st->cur_b, c = st->cur_c;
-    const int x = slot < nlive ? slot_id[slot] : -1;
-    bool live = x >= 0 && x != c;
-    const int sx = live ? asz[x] : 0;
-    live = live && sx > 0;
-    const int sc = asz[c];
-    const bool act = live && (sx + sc <= max_size); // else: banned for good (static mask); value never read
-    if (!__any(act)) return;                         // same 64 slots in every wave: a workgroup-uniform exit
-    // CT4 and cnew carry dqp + UPD_PAD_G zero-padded groups: padded k contribute (0-0)^2 = +0 exactly and no load
-    // in the pipeline needs a guard.
+    // ---- every load that does not depend on the step's state is issued FIRST, so the kernel pays two dependent
+    // memory round trips (state -> sizes) before its pipeline runs instead of six ----
+    const int done = st->done, valid = st->cur_valid, nlive = st->nlive;
+    const int a = st->cur_a, b = st->cur_b, c = st->cur_c, sa = st->cur_sa, sb = st->cur_sb, mv_from = st->mv_from, mv_to = st->mv_to;
+    const bool mover = blockIdx.x == gridDim.x - 1;
+    const int64_t slot = mover ? 0 : (int64_t)blockIdx.x * 64 + lane; // S is a multiple of 64
+    const int xraw = slot_id[slot];
     // column loads use a scalar row base + one per-lane 32-bit byte offset (the CT4 image is < 4 GiB)
     const char *ctb = reinterpret_cast<const char *>(CT);
     const unsigned voff = (unsigned)slot * 16u;
     const int64_t row_bytes = S * 16;
-    // the new centroid is staged once into LDS: scalar loads would share lgkmcnt with the ring's ds_writes and, being
-    // unordered against them, force lgkmcnt(0) (a full LDS round trip) on every k-group
-    extern __shared__ __attribute__((aligned(16))) float4 cn4[];
-    for (int g = threadIdx.x; g < dqp + UPD_PAD_G; g += UPD_THREADS) cn4[g] = reinterpret_cast<const float4 *>(cnew)[g];
-    __syncthreads();
     const int pj = wave - 1;
-    float s = 0.0f;
     float4 va[UPD_GP], vb[UPD_GP], vc[UPD_GP];
     auto load = [&](float4 (&v)[UPD_GP], int stage) {
         const char *rb = ctb + (int64_t)(stage * UPD_SG + pj * UPD_GP) * row_bytes; // wave-uniform
 #pragma unroll
         for (int u = 0; u < UPD_GP; ++u) v[u] = *reinterpret_cast<const float4 *>(rb + (int64_t)u * row_bytes + voff);
     };
+    constexpr int CNR = 2; // new-centroid float4s staged per thread per pass
+    float4 cnr[CNR];
+#pragma unroll
+    for (int i = 0; i < CNR; ++i) {
+        const int g = threadIdx.x + i * UPD_THREADS;
+        cnr[i] = g < dqp + UPD_PAD_G ? reinterpret_cast<const float4 *>(cnew)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (wave > 0 && !mover) { // speculative: harmless when the workgroup turns out to have nothing to do
+        load(va, 0);
+        load(vb, 1);
+    }
+    if (done || !valid) return;
+    if (mover) { // compaction copy (disjoint from every column read below: mv_to is a free slot)
+        if (mv_to < 0) return;
+        const int dq = (d + 3) >> 2;
+        for (int g = threadIdx.x; g < dq; g += UPD_THREADS)
+            *reinterpret_cast<float4 *>(CT + ct4_off(g, S, mv_to)) = *reinterpret_cast<const float4 *>(CT + ct4_off(g, S, mv_from));
+        for (int k = threadIdx.x; k < d; k += UPD_THREADS) Crow[(int64_t)mv_to * d + k] = Crow[(int64_t)mv_from * d + k];
+        return;
+    }
+    if ((int64_t)blockIdx.x * 64 >= nlive) return;
+    const int x = slot < nlive ? xraw : -1;
+    bool live = x >= 0 && x != c;
+    const int sx = live ? asz[x] : 0;
+    live = live && sx > 0;
+    const int sc = sa + sb; // == asz[c]
+    const bool act = live && (sx + sc <= max_size); // else: banned for good (static mask); value never read
+    if (!__any(act)) return;                         // same 64 slots in every wave: a workgroup-uniform exit
+    // CT4 and cnew carry dqp + UPD_PAD_G zero-padded groups: padded k contribute (0-0)^2 = +0 exactly and no load
+    // in the pipeline needs a guard.
+    // the new centroid is staged once into LDS: scalar loads would share lgkmcnt with the ring's ds_writes and, being
+    // unordered against them, force lgkmcnt(0) (a full LDS round trip) on every k-group
+    float4 *cn4 = upd_lds + 2 * UPD_SG * 64;
+#pragma unroll
+    for (int i = 0; i < CNR; ++i) {
+        const int g = threadIdx.x + i * UPD_THREADS;
+        if (g < dqp + UPD_PAD_G) cn4[g] = cnr[i];
+    }
+    for (int g = threadIdx.x + CNR * UPD_THREADS; g < dqp + UPD_PAD_G; g += UPD_THREADS) cn4[g] = reinterpret_cast<const float4 *>(cnew)[g];
+    __syncthreads();
+    float s = 0.0f;
     auto produce = [&](const float4 (&v)[UPD_GP], int stage, int buf) {
         const int g0 = stage * UPD_SG + pj * UPD_GP;
 #pragma unroll
@@ -729,22 +749,22 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
         }
     };
     auto consume = [&](int buf) {
+        // all of the stage's reads are issued at once, right behind the barrier, so they sit in the LDS queue AHEAD of the
+        // producers' next 24 KiB of ds_write_b128 (measured: reads issued later wait ~300 cycles behind those writes)
+        float4 p[UPD_SG];
+#pragma unroll
+        for (int g = 0; g < UPD_SG; ++g) p[g] = ring[buf][g][lane];
 #pragma unroll
         for (int g = 0; g < UPD_SG; ++g) {
-            const float4 p = ring[buf][g][lane];
-            s = s + p.x; // :154 the running sum, strictly in k order
-            s = s + p.y;
-            s = s + p.z;
-            s = s + p.w;
+            s = s + p[g].x; // :154 the running sum, strictly in k order
+            s = s + p[g].y;
+            s = s + p[g].z;
+            s = s + p[g].w;
         }
     };
     // producers keep TWO stages of column loads in flight (3 register sets) so a stage's arithmetic never waits on
     // the memory latency; the p ring in LDS is double-buffered (stage parity)
     const int nstage = dqp / UPD_SG; // multiple of 3
-    if (wave > 0) {
-        load(va, 0);
-        load(vb, 1);
-    }
     for (int i = 0; i < nstage; i += 3) {
         if (wave > 0) {
             load(vc, i + 2);
@@ -1141,8 +1161,13 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // the loop is captured ONCE into a hipGraph of GRAPH_STEPS steps and replayed (launch-bound inner loop).
     const unsigned upd_blocks = (unsigned)(w->S / 64) + 2; // 64 slots per workgroup + preselect + compaction workgroups
     const int dqp = (int)upd_groups(d);
-    const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16; // new centroid image; the p ring is static (48 KiB)
-    if (upd_lds > 100 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+    const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16 + (size_t)2 * UPD_SG * 64 * 16; // new centroid image + p ring
+    if (upd_lds > 160 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+    static bool upd_attr = false;
+    if (!upd_attr) {
+        (void)hipFuncSetAttribute((const void *)ward_update_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        upd_attr = true;
+    }
     auto finish = [&]() {
         hipLaunchKernelGGL(ward_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
                            w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->st);
