@@ -5,8 +5,11 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
     u8 images (per rank) -> ResNet50-v1 bf16 embed (batch 256) -> [N>1: RCCL all-gather of E over xGMI]
     -> size-constrained Ward (min=5, max=50, exact update: cluster ids bit-identical to the reference)
     -> cluster_id[N] on the host.
-N=1 runs BASELINE.json configs[1] (10 000 synthetic 224x224x3 images, 1 GPU).  N>1 is weak scaling: every rank
-embeds the same number of images; rank 0 clusters the gathered E (configs[2]'s shape: "Ward on GPU0").
+N=1 runs BASELINE.json configs[1] (10 000 synthetic 224x224x3 images, 1 GPU).  N>1 defaults to STRONG scaling of the
+same 10 000-image job ("images/sec ... at 1/2/4/8 MI355X" of one dataset): the images are sharded over the ranks for the
+embed, E is all-gathered, rank 0 clusters it (configs[2]'s shape: "Ward on GPU0").  The Ward merge loop is sequential
+and stays on one GPU, so the speed-up is Amdahl-limited by it; `--scaling weak` keeps 10 000 images PER GPU instead
+(the clustered set then grows with N and Ward's O(N^2 D) work dominates).
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -66,7 +69,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images-per-gpu", type=int, default=10000)
+    ap.add_argument("--total-images", type=int, default=10000, help="strong scaling: images of the whole job")
+    ap.add_argument("--images-per-gpu", type=int, default=10000, help="weak scaling: images per rank")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL over xGMI, the product path); gloo stages the gather through host memory and lets several "
+                         "ranks share one GPU -- only for rehearsing the N>1 control flow on a 1-GPU box")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--min-size", type=int, default=5)
     ap.add_argument("--max-size", type=int, default=50)
@@ -91,12 +99,14 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         from imageclust_amd import distributed as D0
 
-        D0.init("nccl", rank, world, dev)  # nccl == RCCL on ROCm (xGMI inside the node)
+        D0.init(args.dist_backend, rank, world, dev)  # nccl == RCCL on ROCm (xGMI inside the node)
 
     from imageclust_amd import _lib
     from imageclust_amd import distributed as D
@@ -104,15 +114,19 @@ def main():
     ctx = _lib.Context(local_rank)
     ctx.load_synthetic(1)
     ctx.set_batch(args.batch)
-    n_local = args.images_per_gpu
-    n_total = n_local * world
+    if args.scaling == "weak":
+        n_total = args.images_per_gpu * world
+    else:
+        n_total = args.total_images
+    lo, hi = D.shard_range(n_total, rank, world)
+    n_local = hi - lo
     DIM = _lib.HEAD_POOLED
 
     # synthetic inputs, generated on-device and resident in HBM before any timed region
-    imgs = torch.empty(n_local * _lib.IMG_BYTES, dtype=torch.uint8, device=dev)
-    ctx.synth_images_dev(20250217, rank * n_local, n_local, _lib.SYNTH_STRUCTURED, imgs.data_ptr())
+    imgs = torch.empty(max(n_local, 1) * _lib.IMG_BYTES, dtype=torch.uint8, device=dev)
+    ctx.synth_images_dev(20250217, lo, n_local, _lib.SYNTH_STRUCTURED, imgs.data_ptr())
     ctx.sync()
-    E_local = torch.empty((n_local, DIM), dtype=torch.float32, device=dev)
+    E_local = torch.empty((max(n_local, 1), DIM), dtype=torch.float32, device=dev)[:n_local]
     update = _lib.UPDATE_LW if args.update == "lw" else _lib.UPDATE_EXACT
     result = {}
 
@@ -123,7 +137,10 @@ def main():
         E_full = E_local
         if world > 1:
             t0 = time.perf_counter()
-            E_full = D.gather_embeddings(E_local, n_total, rank, world)  # ONE RCCL all-gather, shard order
+            if args.dist_backend == "nccl":
+                E_full = D.gather_embeddings(E_local, n_total, rank, world)  # ONE RCCL all-gather, shard order
+            else:
+                E_full = D.gather_embeddings(E_local.cpu(), n_total, rank, world).to(dev)
             torch.cuda.synchronize()
             result["allgather_ms"] = (time.perf_counter() - t0) * 1e3
         if args.embed_only:
@@ -152,7 +169,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(0)
-    elapsed = D.max_over_ranks(elapsed, dev)
+    elapsed = D.max_over_ranks(elapsed, dev if args.dist_backend == "nccl" else None)
 
     if rank == 0:
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -174,11 +191,11 @@ def main():
         out = {
             "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic 224x224x3 images per GPU (structured, seed 20250217), ResNet50-v1 bf16 "
+            "config": {"workload": "configs[1]: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 bf16 "
                                    "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d on GPU0 -> cluster ids on host"
-                                   % (n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
+                                   % (n_total, n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
                        "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
                        "ward_update": "exact (ids bit-identical to the reference)" if args.update == "exact"
                        else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},
