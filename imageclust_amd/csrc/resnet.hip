@@ -49,24 +49,11 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     constexpr int NT = BN / 64;
     constexpr int EP_LD = BN + 4; // fp32 epilogue tile row stride (floats)
     float *ep = reinterpret_cast<float *>(smem);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int ml = wm * 64 + b * 32 + fr;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
-                *reinterpret_cast<float4 *>(ep + ml * EP_LD + nl) =
-                    make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-            }
-    }
-    __syncthreads();
     elem *Yg = (elem *)p.Y;
     const elem *Rg = (const elem *)p.R;
     constexpr int CPR = BN / T::KE;   // 16-byte output chunks per tile row
     constexpr int RPP = 256 / CPR;    // tile rows covered per pass
-    constexpr int NPASS = CV_BM / RPP;
+    constexpr int NPASS = 64 / RPP;   // passes per 64-row half tile
     const int nl = (tid % CPR) * T::KE;
     float sc[T::KE], sh[T::KE];
 #pragma unroll
@@ -76,43 +63,64 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
         sc[q] = a4.x; sc[q + 1] = a4.y; sc[q + 2] = a4.z; sc[q + 3] = a4.w;
         sh[q] = b4.x; sh[q + 1] = b4.y; sh[q + 2] = b4.z; sh[q + 3] = b4.w;
     }
-    // all residual loads of the lane are issued before any arithmetic: NPASS x 16 B in flight per lane
-    uint4 rv[NPASS];
-    if (Rg) {
+    // the 128-row tile goes through LDS in two 64-row halves (the waves with wm == half own those rows): the
+    // epilogue then needs 64 x (BN+4) x 4 B of LDS, which lets single-k-step layers run 4 workgroups per CU
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        // all residual loads of the lane for this half are issued before any arithmetic
+        uint4 rv[NPASS];
+        if (Rg) {
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int64_t m = row_m(half * 64 + tid / CPR + i * RPP);
+                rv[i] = m < p.M ? *reinterpret_cast<const uint4 *>(Rg + m * p.Cout + n0 + nl) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (half) __syncthreads(); // everybody finished reading the first half
+        if (wm == half) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ml = b * 32 + fr;
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nn = wn * (BN / 2) + a * 32 + 8 * g + 4 * fh;
+                        *reinterpret_cast<float4 *>(ep + ml * EP_LD + nn) =
+                            make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+                    }
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int64_t m = row_m(tid / CPR + i * RPP);
-            rv[i] = m < p.M ? *reinterpret_cast<const uint4 *>(Rg + m * p.Cout + n0 + nl) : make_uint4(0, 0, 0, 0);
+            const int ml = tid / CPR + i * RPP;
+            const int64_t m = row_m(half * 64 + ml);
+            if (m >= p.M) break;
+            float v[T::KE];
+#pragma unroll
+            for (int q = 0; q < T::KE; q += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(ep + ml * EP_LD + nl + q);
+                v[q] = t.x * sc[q] + sh[q];
+                v[q + 1] = t.y * sc[q + 1] + sh[q + 1];
+                v[q + 2] = t.z * sc[q + 2] + sh[q + 2];
+                v[q + 3] = t.w * sc[q + 3] + sh[q + 3];
+            }
+            if (Rg) {
+                const elem *re = reinterpret_cast<const elem *>(&rv[i]);
+#pragma unroll
+                for (int q = 0; q < T::KE; ++q) v[q] += T::to_f(re[q]);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+            }
+            uint4 ov;
+            elem *oe = reinterpret_cast<elem *>(&ov);
+#pragma unroll
+            for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
+            *reinterpret_cast<uint4 *>(Yg + m * p.Cout + n0 + nl) = ov;
         }
-    }
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int ml = tid / CPR + i * RPP;
-        const int64_t m = row_m(ml);
-        if (m >= p.M) break;
-        float v[T::KE];
-#pragma unroll
-        for (int q = 0; q < T::KE; q += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(ep + ml * EP_LD + nl + q);
-            v[q] = t.x * sc[q] + sh[q];
-            v[q + 1] = t.y * sc[q + 1] + sh[q + 1];
-            v[q + 2] = t.z * sc[q + 2] + sh[q + 2];
-            v[q + 3] = t.w * sc[q + 3] + sh[q + 3];
-        }
-        if (Rg) {
-            const elem *re = reinterpret_cast<const elem *>(&rv[i]);
-#pragma unroll
-            for (int q = 0; q < T::KE; ++q) v[q] += T::to_f(re[q]);
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
-        }
-        uint4 ov;
-        elem *oe = reinterpret_cast<elem *>(&ov);
-#pragma unroll
-        for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
-        *reinterpret_cast<uint4 *>(Yg + m * p.Cout + n0 + nl) = ov;
     }
 }
 
@@ -216,9 +224,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 }
 
 template <int BN>
-static constexpr size_t conv_lds_bytes()
+static constexpr size_t conv_lds_bytes(int nstages = 2)
 {
-    const size_t stages = 2 * (size_t)(BN + CV_BM) * CV_ROWB, ep = (size_t)CV_BM * (BN + 4) * 4;
+    const size_t stages = (size_t)nstages * (BN + CV_BM) * CV_ROWB, ep = (size_t)64 * (BN + 4) * 4;
     return stages > ep ? stages : ep;
 }
 
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
 template <typename T>
 static constexpr size_t stem_lds_bytes()
 {
-    const size_t st = (size_t)(STEM_K / T::BK) * 64 * CV_ROWB + 2 * (size_t)CV_BM * CV_ROWB + STEM_PH * STEM_PW + 16, ep = (size_t)CV_BM * (64 + 4) * 4;
+    const size_t st = (size_t)(STEM_K / T::BK) * 64 * CV_ROWB + 2 * (size_t)CV_BM * CV_ROWB + STEM_PH * STEM_PW + 16, ep = (size_t)64 * (64 + 4) * 4;
     return st > ep ? st : ep;
 }
 
@@ -671,12 +679,13 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     }
     a.gx = (int)icl_ceil_div(a.M, CV_BM);
     icl_prof_scope ps(ctx, a.Cout % 128 == 0 ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    const int nst = a.K / T::BK > 1 ? 2 : 1; // single-k-step layers need one stage only -> more workgroups per CU
     if (a.Cout % 128 == 0) {
         a.gy = a.Cout / 128;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(), ctx->stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(nst), ctx->stream, a);
     } else {
         a.gy = a.Cout / 64;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<64>(), ctx->stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<64>(nst), ctx->stream, a);
     }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
