@@ -33,6 +33,10 @@ struct conv_args {
     int64_t M;          // B*Ho*Wo
     int K;              // KH*KW*Cin
     int gx, gy;         // tiles along M and along Cout
+    // optional second operand (DUAL kernels): a 1x1 / stride2 convolution over X2 accumulated into the SAME tile, i.e.
+    // the K axis is [KH*KW*Cin of X | Cin2 of X2].  Used to fuse a bottleneck's downsample branch into its last conv.
+    const void *X2;     // [B][H2][W2][Cin2]
+    int H2, W2, Cin2, stride2;
 };
 
 // Epilogue: y = relu(acc*scale + shift (+ residual)).
@@ -124,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 {
     typedef typename T::elem elem;
@@ -149,6 +153,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
     int xiy[XI], xix[XI];
     bool xok[XI];
     int xls[XI]; // logical k-chunk this lane fetches for its row (source-side swizzle)
+    int64_t xbase2[DUAL ? XI : 1];
+    const elem *X2g = (const elem *)p.X2;
+    const int K1 = p.KH * p.KW * p.Cin; // k-steps below K1 read X, the rest read X2
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int row = wid * (CV_BM / 4) + i * 8 + prow;
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         xix[i] = ox * p.stride - p.pad;
         xbase[i] = (((int64_t)b * p.H + xiy[i]) * p.W + xix[i]) * p.Cin;
         xls[i] = lds_swz(row, ps);
+        if (DUAL) xbase2[i] = (((int64_t)b * p.H2 + (int64_t)oy * p.stride2) * p.W2 + (int64_t)ox * p.stride2) * p.Cin2;
     }
     int64_t wbase[WI];
 #pragma unroll
@@ -188,6 +196,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         const unsigned xdst = smem_base + buf * STAGE + wave_x;
 #pragma unroll
         for (int i = 0; i < WI; ++i) glds16_asm(Wg + wbase[i] + k0, wdst + i * 8 * CV_ROWB);
+        if (DUAL && k0 >= K1) { // second operand: plain channel run of the strided pixel
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const elem *src = xok[i] ? X2g + xbase2[i] + (k0 - K1) + xls[i] * T::KE : (const elem *)p.zero;
+                glds16_asm(src, xdst + i * 8 * CV_ROWB);
+            }
+            k0 += T::BK;
+            return;
+        }
         const int64_t tap_off = ((int64_t)kh * p.W + kw) * p.Cin + ci0;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -416,6 +433,9 @@ struct conv_layer {
     int K = 0, cin_eff = 0; // cin_eff: channel count seen by the kernel (160 for the lowered stem)
     void *w[2] = {nullptr, nullptr}; // [ICL_PREC_FP32], [ICL_PREC_BF16]
     float *scale = nullptr, *shift = nullptr;
+    // block-0 c3 only: [Cout][mid + cin] = [W3*scale3 | Wds*scale_ds] and shift3 + shift_ds (downsample fused in)
+    void *wfused[2] = {nullptr, nullptr};
+    float *shift_fused = nullptr;
 };
 
 struct icl_model {
@@ -426,6 +446,7 @@ struct icl_model {
     void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *pooled = nullptr;
     void *zero = nullptr; // 256 zero bytes: LDS-DMA source for padded taps
+    float *ones = nullptr; // [2048] scale of the fused layers (their BN scale is folded into the weights)
     int ws_batch = 0, ws_prec = -1;
 };
 
@@ -534,10 +555,10 @@ void icl_model_free(icl_ctx *ctx)
     icl_model *m = ctx->model;
     if (!m) return;
     for (auto &c : m->conv) {
-        for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift})
+        for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift, c.wfused[0], c.wfused[1], (void *)c.shift_fused})
             if (p) (void)hipFree(p);
     }
-    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], (void *)m->pooled, m->zero})
+    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], (void *)m->pooled, m->zero, (void *)m->ones})
         if (p) (void)hipFree(p);
     delete m;
     ctx->model = nullptr;
@@ -572,6 +593,7 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
     std::vector<float> wf;
     std::vector<uint16_t> wb;
     std::vector<float> sc, sh;
+    std::vector<std::vector<float>> hw((size_t)m->nconv), hsc((size_t)m->nconv), hsh((size_t)m->nconv); // host copies for the fusion below
     for (int i = 0; i < m->nconv; ++i) {
         conv_layer &L = m->conv[i];
         L.rec = t[i];
@@ -611,6 +633,34 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
         }
         ICL_TRY(upload(ctx, (void **)&L.scale, sc.data(), (size_t)cout * 4));
         ICL_TRY(upload(ctx, (void **)&L.shift, sh.data(), (size_t)cout * 4));
+        if (t[i].block == 0 && (t[i].role == 3 || t[i].role == 4)) {
+            hw[(size_t)i] = wf;
+            hsc[(size_t)i] = sc;
+            hsh[(size_t)i] = sh;
+        }
+    }
+    // fuse each stage's downsample branch into block 0's last conv: y = relu(W3'.t2 + Wds'.x_strided + (sh3 + sh_ds))
+    for (int i = 0; i < m->nconv; ++i) {
+        if (!(t[i].block == 0 && t[i].role == 3)) continue;
+        const int ids = i + 1; // canonical order: c1, c2, c3, ds
+        const int cout = t[i].cout, k1 = t[i].cin, k2 = t[ids].cin, kk = k1 + k2;
+        wf.assign((size_t)cout * kk, 0.0f);
+        sh.resize((size_t)cout);
+        for (int co = 0; co < cout; ++co) {
+            for (int c = 0; c < k1; ++c) wf[(size_t)co * kk + c] = hw[(size_t)i][(size_t)co * k1 + c] * hsc[(size_t)i][(size_t)co];
+            for (int c = 0; c < k2; ++c) wf[(size_t)co * kk + k1 + c] = hw[(size_t)ids][(size_t)co * k2 + c] * hsc[(size_t)ids][(size_t)co];
+            sh[(size_t)co] = hsh[(size_t)i][(size_t)co] + hsh[(size_t)ids][(size_t)co];
+        }
+        wb.resize(wf.size());
+        for (size_t e = 0; e < wf.size(); ++e) wb[e] = host_bf16(wf[e]);
+        conv_layer &L = m->conv[i];
+        ICL_TRY(upload(ctx, &L.wfused[ICL_PREC_FP32], wf.data(), wf.size() * 4));
+        ICL_TRY(upload(ctx, &L.wfused[ICL_PREC_BF16], wb.data(), wb.size() * 2));
+        ICL_TRY(upload(ctx, (void **)&L.shift_fused, sh.data(), (size_t)cout * 4));
+    }
+    {
+        std::vector<float> one(2048, 1.0f);
+        ICL_TRY(upload(ctx, (void **)&m->ones, one.data(), one.size() * 4));
     }
     ICL_TRY(upload(ctx, (void **)&m->fcw, p, (size_t)ICL_FC_OUT * ICL_FEAT_DIM * 4));
     p += (int64_t)ICL_FC_OUT * ICL_FEAT_DIM;
@@ -680,7 +730,15 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     a.gx = (int)icl_ceil_div(a.M, CV_BM);
     icl_prof_scope ps(ctx, a.Cout % 128 == 0 ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
     const int nst = a.K / T::BK > 1 ? 2 : 1; // single-k-step layers need one stage only -> more workgroups per CU
-    if (a.Cout % 128 == 0) {
+    if (a.X2) {
+        static bool dual_attr = false;
+        if (!dual_attr) {
+            (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<128>());
+            dual_attr = true;
+        }
+        a.gy = a.Cout / 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128, true>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(2), ctx->stream, a);
+    } else if (a.Cout % 128 == 0) {
         a.gy = a.Cout / 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(nst), ctx->stream, a);
     } else {
@@ -701,6 +759,8 @@ static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *
     a.scale = L.scale;
     a.shift = L.shift;
     a.zero = ctx->model->zero;
+    a.X2 = nullptr;
+    a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
     a.B = B;
     a.relu = relu;
     a.Cout = L.rec.cout;
@@ -767,6 +827,7 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
     if (!rc) {
         conv_args a;
         a.X = dx; a.Wt = dw; a.Y = dy; a.R = dr; a.scale = dsc; a.shift = dsh; a.zero = dz;
+        a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
         a.B = B; a.H = a.W = H; a.Cin = Cin; a.Ho = a.Wo = Ho; a.Cout = Cout; a.KH = a.KW = k; a.stride = stride; a.pad = pad;
         a.relu = relu; a.M = (int64_t)B * Ho * Ho; a.K = k * k * Cin;
         rc = prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
@@ -790,6 +851,37 @@ extern "C" int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, i
     return rc;
 }
 
+// Block 0 of a stage: y = relu(bn3(conv3(t2)) + bn_ds(conv_ds(x))) as ONE dual-operand launch (BN scales folded into
+// the concatenated weights): the downsample tensor is never written to or read back from HBM.
+static int launch_conv_fused_ds(icl_ctx *ctx, int prec, const conv_layer &c3, const conv_layer &ds, const void *t2, const void *x, void *y, int B)
+{
+    conv_args a;
+    a.X = t2;
+    a.Wt = c3.wfused[prec];
+    a.Y = y;
+    a.R = nullptr;
+    a.scale = ctx->model->ones;
+    a.shift = c3.shift_fused;
+    a.zero = ctx->model->zero;
+    a.B = B;
+    a.relu = 1;
+    a.Cout = c3.rec.cout;
+    a.H = a.W = a.Ho = a.Wo = c3.rec.hout;
+    a.Cin = c3.rec.cin;
+    a.KH = a.KW = 1;
+    a.stride = 1;
+    a.pad = 0;
+    a.X2 = x;
+    a.H2 = a.W2 = ds.rec.hin;
+    a.Cin2 = ds.rec.cin;
+    a.stride2 = ds.rec.stride;
+    a.M = (int64_t)B * a.Ho * a.Wo;
+    a.K = a.Cin + a.Cin2;
+    const int bk = prec == ICL_PREC_BF16 ? BF16::BK : F32::BK;
+    if (a.Cin % bk || a.Cin2 % bk || a.Cout % 128) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "fused downsample shape not supported");
+    return prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
+}
+
 template <typename T>
 static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, int head, float *d_out)
 {
@@ -808,6 +900,7 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
         a.X = nullptr; a.Wt = L.w[prec]; a.Y = y; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
         a.B = B; a.H = a.W = 224; a.Cin = 3; a.Ho = a.Wo = 112; a.Cout = 64; a.KH = a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
         a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
+        a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
         icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
         hipLaunchKernelGGL((stem_conv_kernel<T>), dim3((unsigned)a.gx), dim3(256), stem_lds_bytes<T>(), ctx->stream, d_img, a);
     }
@@ -821,12 +914,10 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
         const bool has_ds = c1.rec.block == 0;
         ICL_TRY(launch_conv(ctx, prec, c1, x, t1, nullptr, 1, B));
         ICL_TRY(launch_conv(ctx, prec, c2, t1, t2, nullptr, 1, B));
-        const void *res = x;
-        if (has_ds) {
-            ICL_TRY(launch_conv(ctx, prec, m->conv[ci + 3], x, ds, nullptr, 0, B));
-            res = ds;
-        }
-        ICL_TRY(launch_conv(ctx, prec, c3, t2, y, res, 1, B)); // relu(bn(conv) + residual)
+        if (has_ds)
+            ICL_TRY(launch_conv_fused_ds(ctx, prec, c3, m->conv[ci + 3], t2, x, y, B)); // relu(bn3(conv3) + bn_ds(conv_ds))
+        else
+            ICL_TRY(launch_conv(ctx, prec, c3, t2, y, x, 1, B)); // relu(bn(conv) + residual)
         std::swap(x, y);
         ci += has_ds ? 4 : 3;
     }
