@@ -655,8 +655,8 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
 #define UPD_GP 4                      /* k-groups (float4) per producer per stage */
 #define UPD_THREADS (64 * (UPD_P + 1))
 #define UPD_SG (UPD_P * UPD_GP)       /* k-groups per stage */
-#define UPD_PAD_G (2 * UPD_SG)        /* zero groups past the end so the last prefetches need no guard */
-static inline int64_t upd_groups(int d) { return (((int64_t)d + 3) / 4 + 3 * UPD_SG - 1) / (3 * UPD_SG) * (3 * UPD_SG); }
+#define UPD_PAD_G (4 * UPD_SG)        /* zero groups past the end: the unrolled-by-3 loop may prefetch up to 4 stages beyond */
+static inline int64_t upd_groups(int d) { return (((int64_t)d + 3) / 4 + UPD_SG - 1) / UPD_SG * UPD_SG; } // whole stages
 
 __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                float *__restrict__ Crow, const float *__restrict__ cnew,
@@ -764,26 +764,30 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
     };
     // producers keep TWO stages of column loads in flight (3 register sets) so a stage's arithmetic never waits on
     // the memory latency; the p ring in LDS is double-buffered (stage parity)
-    const int nstage = dqp / UPD_SG; // multiple of 3
+    const int nstage = dqp / UPD_SG; // the loop is unrolled by 3 (register rotation): stages >= nstage are skipped
     for (int i = 0; i < nstage; i += 3) {
         if (wave > 0) {
-            load(vc, i + 2);
+            load(vc, i + 2); // loads past the last stage read the zero padding and are never consumed
             produce(va, i, i & 1);
         }
         __syncthreads();
         if (wave == 0) consume(i & 1);
-        if (wave > 0) {
-            load(va, i + 3); // stages >= nstage: zero padding
-            produce(vb, i + 1, (i + 1) & 1);
+        if (i + 1 < nstage) {
+            if (wave > 0) {
+                load(va, i + 3);
+                produce(vb, i + 1, (i + 1) & 1);
+            }
+            __syncthreads();
+            if (wave == 0) consume((i + 1) & 1);
         }
-        __syncthreads();
-        if (wave == 0) consume((i + 1) & 1);
-        if (wave > 0) {
-            load(vb, i + 4);
-            produce(vc, i + 2, i & 1);
+        if (i + 2 < nstage) {
+            if (wave > 0) {
+                load(vb, i + 4);
+                produce(vc, i + 2, i & 1);
+            }
+            __syncthreads();
+            if (wave == 0) consume(i & 1);
         }
-        __syncthreads();
-        if (wave == 0) consume(i & 1);
     }
     if (wave != 0) return;
     const float num = (float)((int64_t)sx * (int64_t)sc);
