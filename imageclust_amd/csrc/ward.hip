@@ -23,6 +23,26 @@ int icl_dist_mfma_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, float
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+#define WB_K 4 /* merges attempted per batched step */
+#define WB_R 24 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
+struct ward_batch_state {
+    int32_t nb;                                   // tentative picks whose rows the update kernel is computing
+    int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
+    float val[WB_K];                              // Ward value of the pair
+    int32_t pre_n, pre_for_nb;                    // preselection (assumes the nb picks above all commit)
+    int32_t pre_row[WB_K], pre_nn[WB_K], pre_sa[WB_K], pre_sb[WB_K];
+    float pre_val[WB_K];
+    int32_t ov_n, ov_pad;                         // rows re-minimised under the "batch commits" assumption
+    int32_t ov_row[8], ov_nn[8];
+    float ov_val[8];
+    int32_t epoch, spec_pad[3];                   // speculative row re-minimisation by the spare workgroups
+    int32_t spec_row[WB_R], spec_nn[WB_R], spec_done[WB_R];
+    float spec_val[WB_R];
+    int32_t commits, steps, slow, pad;            // statistics
+    unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
+    unsigned long long dbg[8], dbg_t0;
+};
+
 struct ward_state {
     int32_t done;      // no mergeable pair left (clustering.go:222-225)
     int32_t t;         // merges performed so far
@@ -36,6 +56,7 @@ struct ward_state {
     float pre_val;
     int32_t pad;
     unsigned long long ckey; // (value bits << 32 | column id) minimum of the new cluster's row, built with atomicMin
+    ward_batch_state B;      // batched exact mode
 };
 
 struct icl_ward_ws {
@@ -44,7 +65,8 @@ struct icl_ward_ws {
     int64_t S = 0, M = 0;
     float *CT = nullptr;       // [D][S] centroids, transposed: slot-contiguous
     float *Crow = nullptr;     // [S][D] the same centroids, cluster-contiguous (coalesced merge of two centroids)
-    float *cnew = nullptr;     // [D] centroid of the cluster created by the current step
+    float *cnew = nullptr;     // [WB_K][cn_stride] centroids of the clusters created by the current step (batched: up to WB_K)
+    int64_t cn_stride = 0;     // floats per centroid image (zero padded)
     int32_t *slot_id = nullptr;// [S] creation id held by a slot, -1 if free
     int32_t *id_slot = nullptr;// [M]
     int32_t *asz = nullptr;    // [M] size if alive else 0
@@ -64,7 +86,7 @@ struct icl_ward_ws {
     // hipGraph of GRAPH_STEPS merge steps (all step-varying state lives in device memory, so one capture replays)
     hipGraphExec_t graph_exec = nullptr;
     int graph_max_size = -1;
-    bool graph_lw = false;
+    int graph_lw = -1;
 };
 
 void icl_ward_free(icl_ctx *ctx)
@@ -407,6 +429,15 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->pre_row = st->pre_nn = -1;
         st->pre_val = ICL_MAXF;
         st->ckey = ~0ull;
+        st->B.nb = 0;
+        st->B.pre_n = 0;
+        st->B.pre_for_nb = -1;
+        st->B.commits = st->B.steps = st->B.slow = 0;
+        st->B.epoch = 1;
+        st->B.ov_n = 0;
+        for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = 0;
+        for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = ~0ull;
+        for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
     }
 }
 
@@ -862,6 +893,1021 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
     }
 }
 
+// ============================================================================================================
+// Batched exact mode: up to WB_K INDEPENDENT merges per step.
+//
+// Consecutive merges of the reference rarely touch the cluster that was just created (0 % of the 8900 merges of the
+// 10k-image benchmark), so several of them can share one pass over the centroids: the producers load every column
+// once and square its differences to WB_K new centroids, the chain wave runs WB_K in-order sums interleaved (the
+// dependent-add latency of one hides behind the others), and launch / selection latencies are paid once per batch.
+//
+// Exactness.  A batch is the maximal prefix p_0 < p_1 < ... of the (value,row)-sorted, clean (exact) row-cache
+// candidates whose pairs are pairwise disjoint: every existing pair not in the prefix is lexicographically >= its
+// last element, merging p_i leaves the caches of p_j (j>i) untouched, so the reference's next merges are exactly
+// p_0, p_1, ... UNLESS a pair of a newly created cluster c_i (i<j) precedes p_j.  New rows get the largest row
+// indices, so that happens iff min(row c_i) < value(p_j) strictly.  The picks are therefore only TENTATIVE while
+// their rows are computed; the next finish kernel commits the longest prefix that passes this test and the others
+// simply stay in the caches.  Row c_j is computed against the clusters alive at ITS time: members of p_0..p_j are
+// excluded, c_0..c_{j-1} are included (as "virtual slots" whose columns are the new centroids).
+// ============================================================================================================
+#define WB_P 6
+#define WB_GP 4
+#define WB_SG (WB_P * WB_GP)          /* k-groups per stage */
+#define WB_THREADS (64 * (WB_P + WB_K)) /* WB_K chain waves (one per tentative cluster) + WB_P producers */
+#define WB_PAD_G (4 * WB_SG)
+static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 1) / WB_SG * WB_SG; }
+
+// Preselection for the NEXT batch, assuming the current tentative picks all commit: their members are treated as dead
+// (rows that pointed at them are re-minimised WITHOUT those columns; the results go to an override list that the finish
+// kernel applies only if the whole batch commits), the rows being created are unknown here and are merged in by the
+// finish kernel.  Output: up to WB_K prefix-closed, clean, pairwise disjoint pairs in ascending (value,row) order.
+//
+// One pass over the row caches: every lane keeps its two smallest entries, every wave pops its four smallest with
+// shuffles and appends a SENTINEL (a lower bound for everything it did not report); wave 0 then walks the <= 50
+// entries in ascending order and stops at the first sentinel, so whatever it saw before is exact.
+#define WB_MAXOV 8
+#define WB_WTOP 4
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o < k ? o : k;
+    }
+    return k;
+}
+
+// scan_row with up to 2*WB_K excluded columns (the tentative batch's members)
+__device__ __forceinline__ void scan_row_ex(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
+                                            int max_size, const int *ex, int nex, float &bv, int &bi)
+{
+    bv = ICL_MAXF;
+    bi = -1;
+    int e8[2 * WB_K];
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
+    const int64_t nvec = len >> 2; // packed rows start 16-byte aligned
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        float4 v[4];
+        int4 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const bool has = q < nvec;
+            v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            m[j] = has ? reinterpret_cast<const int4 *>(asz)[q] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            const int mm[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (mm[e] > 0 && mm[e] + my_size <= max_size && vv[e] < bv) {
+                    const int col = (int)(q * 4 + e);
+                    bool ex_hit = false;
+#pragma unroll
+                    for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
+                    if (!ex_hit) {
+                        bv = vv[e];
+                        bi = col;
+                    }
+                }
+            }
+        }
+    }
+    for (int64_t c = nvec * 4 + threadIdx.x; c < len; c += blockDim.x) {
+        const float v = row[c];
+        const int m = asz[c];
+        bool ok = m > 0 && m + my_size <= max_size && v < bv;
+#pragma unroll
+        for (int z = 0; z < 2 * WB_K; ++z) ok &= e8[z] != (int)c;
+        if (ok) {
+            bv = v;
+            bi = (int)c;
+        }
+    }
+}
+
+// Spare workgroup i of the batched update: rows whose cached partner is a member of the tentative batch will be dirty
+// once it commits.  Every spare workgroup enumerates them in the same deterministic order, takes the i-th and
+// re-minimises it without the batch's members; the finish kernel installs the results if the whole batch commits and
+// the preselection (a later workgroup of the same grid) waits for the ones it needs instead of scanning itself.
+__device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
+                                 const int32_t *__restrict__ rownn, const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
+                                 int max_size, ward_state *__restrict__ st, float *sv, int *si)
+{
+    __shared__ int excl[2 * WB_K];
+    __shared__ int wcnt[16];
+    __shared__ int mine[2];
+    if (st->done) return;
+    const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
+    if (nb <= 0 || t0 + nb >= st->target) return;
+    if (threadIdx.x < 2 * WB_K) {
+        const int j = threadIdx.x >> 1;
+        excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
+    }
+    if (threadIdx.x == 0) mine[0] = -1;
+    __syncthreads();
+    int ex[2 * WB_K];
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    // enumerate: thread-strided over int4 groups of rownn; a thread's matches keep their row order
+    const int64_t nvec = (n + t0 + 3) >> 2;
+    int cnt = 0;
+    unsigned long long hits = 0; // bit (4*iter + e) for up to 16 iterations
+    {
+        int it = 0;
+        for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x, ++it) {
+            const int4 nn4 = reinterpret_cast<const int4 *>(rownn)[q];
+            const int nnv[4] = {nn4.x, nn4.y, nn4.z, nn4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool m = false;
+#pragma unroll
+                for (int z = 0; z < 2 * WB_K; ++z) m |= (nnv[e] >= 0) & (nnv[e] == ex[z]);
+                if (m) {
+                    const int r = (int)(q * 4 + e);
+                    bool self = false;
+#pragma unroll
+                    for (int z = 0; z < 2 * WB_K; ++z) self |= r == ex[z];
+                    if (!self && rowmin[r] < ICL_MAXF) { // alive rows only (dead rows hold MaxFloat32)
+                        ++cnt;
+                        if (it < 16) hits |= 1ull << (4 * it + e);
+                    }
+                }
+            }
+        }
+    }
+    // exclusive prefix over threads
+    int inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wcnt[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w2 = 0; w2 < wave; ++w2) base += wcnt[w2];
+    const int first = base + inc - cnt;
+    // the match with global index wg is mine (concurrent write-backs by the preselection may make two workgroups
+    // disagree on the enumeration: every workgroup therefore publishes the row it actually scanned)
+    if (cnt > 0 && first <= wg && wg < first + cnt) {
+        int idx = first, it = 0;
+        for (int64_t q = threadIdx.x; q < nvec && it < 16; q += blockDim.x, ++it) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((hits >> (4 * it + e)) & 1ull) {
+                    if (idx == wg) mine[0] = (int)(q * 4 + e);
+                    ++idx;
+                }
+        }
+    }
+    __syncthreads();
+    const int r = mine[0];
+    float rv = ICL_MAXF;
+    int ri = -1;
+    if (r >= 0) {
+        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri);
+        block_argmin(rv, ri, sv, si);
+    }
+    if (threadIdx.x == 0) {
+        st->B.spec_row[wg] = r;
+        st->B.spec_val[wg] = rv;
+        st->B.spec_nn[wg] = ri;
+        __threadfence();
+        __hip_atomic_store(&st->B.spec_done[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
+                                     const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int max_size,
+                                     ward_state *__restrict__ st, float *sv, int *si, int *sh)
+{
+    __shared__ int excl[2 * WB_K];
+    __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
+    __shared__ int cmd[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    if (st->done) return;
+    const int nb = st->B.nb, t0 = st->t, target = st->target;
+    const int t_after = t0 + nb;
+    if (t_after >= target) { // nothing left to select for
+        if (threadIdx.x == 0) {
+            st->B.pre_n = 0;
+            st->B.ov_n = 0;
+            st->B.pre_for_nb = nb;
+        }
+        return;
+    }
+    if (threadIdx.x < 2 * WB_K) {
+        const int j = threadIdx.x >> 1;
+        excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
+    }
+    __syncthreads();
+    int ex[2 * WB_K];
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
+    // ---- one pass: per-lane two smallest (value,row) keys; the batch's own members are skipped (dead if it commits)
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    {
+        const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (e[i] < ICL_MAXF) {
+                        const unsigned r = (unsigned)(q * 4 + i);
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(e[i]) << 32) | (r << 1);
+                        if (k < k2) {
+                            bool hit = false;
+#pragma unroll
+                            for (int z = 0; z < 2 * WB_K; ++z) hit |= ex[z] == (int)r;
+                            if (!hit) {
+                                if (k < k1) {
+                                    k2 = k1;
+                                    k1 = k;
+                                } else
+                                    k2 = k;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- per wave: pop the WB_WTOP smallest, then a sentinel = lower bound of the rest of the wave
+    {
+        unsigned long long head = k1;
+        int stg = 0; // 0: head = k1, 1: head = k2, 2: head = sentinel(k2)
+        bool ended = false;
+        for (int q = 0; q < WB_WTOP; ++q) {
+            const unsigned long long m = ended ? ~0ull : wave_min_u64(head);
+            if (lane == 0) wstream[wave * (WB_WTOP + 1) + q] = m;
+            if (m == ~0ull || (m & 1ull)) { // nothing left / a lane ran out of known entries: the wave's list ends here
+                ended = true;
+                continue;
+            }
+            if (head == m) { // keys are unique (distinct rows)
+                ++stg;
+                head = stg == 1 ? k2 : (k2 == ~0ull ? ~0ull : (k2 | 1ull));
+            }
+        }
+        const unsigned long long rest = ended ? ~0ull : wave_min_u64(head);
+        if (lane == 0) wstream[wave * (WB_WTOP + 1) + WB_WTOP] = rest == ~0ull ? rest : (rest | 1ull);
+    }
+    __syncthreads();
+    // ---- wave 0 owns the candidate list (one entry per lane) and resolves it; rescans use the whole workgroup
+    unsigned long long key = ~0ull;
+    int nn = -1, nsz = 0, rsz = 0;
+    bool nn_alive = false;
+    if (wave == 0) {
+        if (lane < nwave * (WB_WTOP + 1)) key = wstream[lane];
+        if (key != ~0ull && !(key & 1ull)) {
+            const int r = (int)((key & 0xffffffffull) >> 1);
+            nn = rownn[r];
+            rsz = asz[r];
+            nsz = nn >= 0 ? asz[nn] : 0;
+            nn_alive = nsz > 0;
+        }
+    }
+    if (threadIdx.x == 0) st->B.dbg[7] += wall_clock64() - st->B.dbg_t0;
+    int npick = 0, nov = 0, nresc = 0;
+    const int epoch = st->B.epoch;
+    int spl_row = -1, spl_nn = -1, spl_n = -1; // lane l: result of spare workgroup l (loaded on first use)
+    float spl_val = ICL_MAXF;
+    int pm[2 * WB_K]; // members of the picks made here
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) pm[z] = -1;
+    for (;;) {
+        if (wave == 0) {
+            int action = 0, arow = -1, alane = -1; // 0 stop, 2 rescan + write back, 3 speculative rescan (override)
+            while (npick < WB_K && t_after + npick < target) {
+                const unsigned long long m = wave_min_u64(key);
+                if (m == ~0ull || (m & 1ull)) break; // exhausted / coverage ends
+                const int src = __ffsll((long long)__ballot(key == m)) - 1;
+                const int r = (int)((m & 0xffffffffull) >> 1);
+                const int rn = __shfl(nn, src, 64);
+                const int ralive = __shfl((int)nn_alive, src, 64);
+                if (rn < 0) { // no partner at all: drop
+                    if (lane == src) key = ~0ull;
+                    continue;
+                }
+                if (!ralive) { // its cached partner has really died: exact rescan, written back
+                    action = 2;
+                    arow = r;
+                    alane = src;
+                    break;
+                }
+                bool in_batch = false, in_picks = false;
+#pragma unroll
+                for (int z = 0; z < 2 * WB_K; ++z) {
+                    in_batch |= ex[z] == rn;
+                    in_picks |= (pm[z] == rn) | (pm[z] == r);
+                }
+                if (in_picks) break; // shares a cluster with an earlier pick: the prefix ends here
+                if (in_batch) {      // partner dies if the batch commits: re-minimise without the batch's members
+                    if (spl_n < 0) { // the spare workgroups' results (they run ahead of this workgroup in the grid)
+                        int ok = lane >= WB_R;
+                        for (int spin = 0; spin < 20000 && !ok; ++spin) {
+                            ok = __hip_atomic_load(&st->B.spec_done[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                            if (!ok) __builtin_amdgcn_s_sleep(4);
+                        }
+                        spl_n = __all(ok) ? WB_R : 0;
+                        if (spl_n && lane < WB_R) {
+                            spl_row = __hip_atomic_load(&st->B.spec_row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            spl_nn = __hip_atomic_load(&st->B.spec_nn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            spl_val = __hip_atomic_load(&st->B.spec_val[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const unsigned long long hm = __ballot(lane < spl_n && spl_row == r);
+                    if (hm) {
+                        const int idx = __ffsll((long long)hm) - 1;
+                        const int sn = __shfl(spl_nn, idx, 64);
+                        const float sval = __shfl(spl_val, idx, 64);
+                        if (lane == src) {
+                            if (sn < 0) {
+                                key = ~0ull;
+                                nn = -1;
+                            } else {
+                                key = ((unsigned long long)__float_as_uint(sval) << 32) | ((unsigned)r << 1);
+                                nn = sn;
+                                nsz = asz[sn];
+                                nn_alive = true;
+                            }
+                        }
+                        continue; // the finish kernel installs this result itself
+                    }
+                    if (nov >= WB_MAXOV) break;
+                    action = 3;
+                    arow = r;
+                    alane = src;
+                    break;
+                }
+                if (lane == 0) {
+                    st->B.pre_row[npick] = r;
+                    st->B.pre_nn[npick] = rn;
+                    st->B.pre_val[npick] = __uint_as_float((unsigned)(m >> 32));
+                }
+                const int s_r = __shfl(rsz, src, 64), s_n = __shfl(nsz, src, 64);
+                if (lane == 0) {
+                    st->B.pre_sa[npick] = s_r;
+                    st->B.pre_sb[npick] = s_n;
+                }
+#pragma unroll
+                for (int z = 0; z < WB_K; ++z)
+                    if (z == npick) {
+                        pm[2 * z] = r;
+                        pm[2 * z + 1] = rn;
+                    }
+                ++npick;
+                if (lane == src) key = ~0ull;
+            }
+            if (action && nresc >= 3 * WB_K) action = 0; // bound the work of one step
+            if (lane == 0) {
+                cmd[0] = action;
+                cmd[1] = arow;
+                cmd[2] = alane;
+            }
+        }
+        __syncthreads();
+        const int action = cmd[0], r = cmd[1], alane = cmd[2];
+        if (action == 0) break;
+        ++nresc;
+        float rv;
+        int ri;
+        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri);
+        block_argmin(rv, ri, sv, si); // ends with a barrier: cmd may be rewritten afterwards
+        if (wave == 0) {
+            if (lane == alane) {
+                if (ri < 0) {
+                    key = ~0ull;
+                    nn = -1;
+                } else {
+                    key = ((unsigned long long)__float_as_uint(rv) << 32) | ((unsigned)r << 1);
+                    nn = ri;
+                    nsz = asz[ri];
+                    nn_alive = true;
+                }
+            }
+            if (lane == 0) {
+                if (action == 2) {
+                    rowmin[r] = rv;
+                    rownn[r] = ri;
+                } else {
+                    st->B.ov_row[nov] = r;
+                    st->B.ov_val[nov] = rv;
+                    st->B.ov_nn[nov] = ri;
+                }
+            }
+            if (action == 3) ++nov;
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->B.pre_n = npick;
+        st->B.ov_n = nov;
+        st->B.pre_for_nb = nb;
+        st->B.dbg[6] += nresc;
+    }
+}
+
+// update for a batch: rows of up to WB_K tentative clusters in one pass over the centroids.
+__global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, int dqp, int64_t S, const float *__restrict__ CT,
+                                                                      const float *__restrict__ cnewK, int64_t cn_stride,
+                                                                      const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                                      const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                                      ward_state *__restrict__ st, int max_size, int64_t n,
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // [2][WB_SG][64] x ring, then [WB_K][dqp+pad] centroids
+    float4 (*ring)[WB_SG][64] = reinterpret_cast<float4 (*)[WB_SG][64]>(wb_lds);
+    // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
+    if (blockIdx.x < WB_R) {
+        float *sv = reinterpret_cast<float *>(wb_lds);
+        int *si = reinterpret_cast<int *>(sv + 16);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
+        return;
+    }
+    if (blockIdx.x == WB_R) {
+        float *sv = reinterpret_cast<float *>(wb_lds);
+        int *si = reinterpret_cast<int *>(sv + 16);
+        int *sh = si + 16;
+        const unsigned long long t0 = wall_clock64();
+        if (threadIdx.x == 0) st->B.dbg_t0 = t0;
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long tm0 = wall_clock64();
+    const bool virt = blockIdx.x == WB_R + 1; // "virtual slots": lane i = tentative cluster c_i, column = its new centroid
+    const int64_t mblk = (int64_t)blockIdx.x - (WB_R + 2);
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    int pa[WB_K], pb[WB_K], psc[WB_K];
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) {
+        pa[j] = st->B.a[j];
+        pb[j] = st->B.b[j];
+        psc[j] = st->B.sa[j] + st->B.sb[j];
+    }
+    const int64_t slot = virt ? lane : mblk * 64 + lane;
+    const int xraw = virt ? -1 : slot_id[slot];
+    const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
+    const unsigned voff = virt ? (unsigned)((lane < WB_K ? lane : 0) * cn_stride * 4) : (unsigned)slot * 16u;
+    const int64_t row_bytes = virt ? 16 : S * 16;
+    const int pj = wave - WB_K; // producer index (waves WB_K..), chain index = wave (waves 0..WB_K-1)
+    const bool producer = wave >= WB_K;
+    struct xq { float4 g0, g1, g2, g3; }; // WB_GP == 4 k-groups of one slot, kept in named registers
+    static_assert(WB_GP == 4, "xq holds four groups");
+    auto load = [&](int stage) {
+        const char *rb = ctb + (int64_t)(stage * WB_SG + pj * WB_GP) * row_bytes + voff;
+        xq v;
+        v.g0 = *reinterpret_cast<const float4 *>(rb);
+        v.g1 = *reinterpret_cast<const float4 *>(rb + row_bytes);
+        v.g2 = *reinterpret_cast<const float4 *>(rb + 2 * row_bytes);
+        v.g3 = *reinterpret_cast<const float4 *>(rb + 3 * row_bytes);
+        return v;
+    };
+    xq va = {}, vb = {}, vc = {};
+    if (producer) {
+        va = load(0);
+        vb = load(1);
+    }
+    if (done || nb <= 0) return;
+    if (!virt && mblk * 64 >= nlive) return;
+    // which rows does this lane's cluster take part in?
+    int x, sx;
+    if (virt) {
+        x = lane < nb ? (int)(n + t + lane) : -1;
+        sx = 0;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j)
+            if (lane == j) sx = psc[j];
+    } else {
+        x = slot < nlive ? xraw : -1;
+        sx = x >= 0 ? asz[x] : 0;
+    }
+    unsigned okmask = 0;
+    {
+        bool alive = x >= 0 && sx > 0;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j) {
+            if (j < nb) {
+                if (virt) {
+                    if (alive && lane < j && sx + psc[j] <= max_size) okmask |= 1u << j;
+                } else {
+                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
+                }
+            }
+        }
+    }
+    if (!__any(okmask != 0)) return;
+    float4 *cn4 = wb_lds + 2 * WB_SG * 64;
+    const int cnl = dqp + WB_PAD_G; // float4s per centroid image in LDS
+    for (int j = 0; j < nb; ++j)
+        for (int g = threadIdx.x; g < cnl; g += WB_THREADS) cn4[j * cnl + g] = reinterpret_cast<const float4 *>(cnewK + j * cn_stride)[g];
+    __syncthreads();
+    float s = 0.0f;
+    // producers only move x (global -> LDS); every chain wave squares its own differences: the 8 VALU instructions per
+    // 4 k (2 pk_sub, 2 pk_mul, 4 dependent adds) issue in about the time the 4 dependent adds take anyway, and the ring
+    // is written once per column instead of once per (column, chain) -- ds_write_b128 is the expensive LDS operation
+    auto produce = [&](const xq &v, int buf) {
+        ring[buf][pj * WB_GP + 0][lane] = v.g0;
+        ring[buf][pj * WB_GP + 1][lane] = v.g1;
+        ring[buf][pj * WB_GP + 2][lane] = v.g2;
+        ring[buf][pj * WB_GP + 3][lane] = v.g3;
+    };
+    const bool chain = wave < nb;
+    const float4 *cnj = cn4 + (chain ? wave : 0) * cnl;
+    auto consume = [&](int buf, int stage) {
+        const float4 *cs = cnj + stage * WB_SG;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 xv[WB_SG / 2], cv[WB_SG / 2];
+#pragma unroll
+            for (int g = 0; g < WB_SG / 2; ++g) {
+                xv[g] = ring[buf][h * (WB_SG / 2) + g][lane];
+                cv[g] = cs[h * (WB_SG / 2) + g];
+            }
+#pragma unroll
+            for (int g = 0; g < WB_SG / 2; ++g) {
+                const f2 xa = {xv[g].x, xv[g].y}, xb = {xv[g].z, xv[g].w};
+                const f2 ca = {cv[g].x, cv[g].y}, cb = {cv[g].z, cv[g].w};
+                const f2 da = xa - ca, db = xb - cb; // clustering.go:139 via :84
+                const f2 qa = da * da, qb = db * db; // :154 products, each rounded
+                s = s + qa.x;                        // :154 the running sum, strictly in k order
+                s = s + qa.y;
+                s = s + qb.x;
+                s = s + qb.y;
+            }
+        }
+    };
+    const int nstage = dqp / WB_SG;
+    for (int i = 0; i < nstage; i += 3) {
+        if (producer) {
+            vc = load(i + 2);
+            produce(va, i & 1);
+        }
+        __syncthreads();
+        if (chain) consume(i & 1, i);
+        if (i + 1 < nstage) {
+            if (producer) {
+                va = load(i + 3);
+                produce(vb, (i + 1) & 1);
+            }
+            __syncthreads();
+            if (chain) consume((i + 1) & 1, i + 1);
+        }
+        if (i + 2 < nstage) {
+            if (producer) {
+                vb = load(i + 4);
+                produce(vc, i & 1);
+            }
+            __syncthreads();
+            if (chain) consume(i & 1, i + 2);
+        }
+    }
+    if (!chain) return;
+    {
+        const int j = wave;
+        unsigned long long key = ~0ull;
+        if ((okmask >> j) & 1u) {
+            int sc = psc[0];
+#pragma unroll
+            for (int q = 1; q < WB_K; ++q)
+                if (j == q) sc = psc[q];
+            const float num = (float)((int64_t)sx * (int64_t)sc);
+            const float den = (float)(sx + sc);
+            const float val = (num / den) * s;
+            const int64_t c = n + t + j;
+            Dtri[rowoff[c] + x] = val;
+            if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
+        if (lane == 0 && j == 0 && mblk == 0) st->B.dbg[1] += wall_clock64() - tm0;
+        if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;
+    }
+}
+
+// finish for a batch: (1) validate + commit the longest valid prefix of the tentative picks (bookkeeping of
+// MergeClusters / RemoveClusters, clustering.go:29-58,:240-241; centroid images into CT4 / Crow; slot compaction);
+// (2) choose the next batch from {rows just created} U {preselected old-row pairs}; (3) merged centroids (:37-40).
+//
+// The slot bookkeeping of up to WB_K commits runs on wave 0 with the touched id_slot / slot_id entries held one per
+// lane (lookup = ballot + shuffle), so the sequential semantics cost no dependent global round trips; the centroid
+// copies need no barriers because a thread owns element k of every slot it touches.
+struct wb_map { // a tiny associative array spread over the lanes of a wave
+    int key, val;
+    __device__ __forceinline__ bool get(int q, int &out) const
+    {
+        const unsigned long long m = __ballot(key == q);
+        if (!m) return false;
+        out = __shfl(val, __ffsll((long long)m) - 1, 64);
+        return true;
+    }
+    __device__ __forceinline__ void set(int q, int v, int &cnt, int lane) // every copy of the key is updated
+    {
+        const unsigned long long m = __ballot(key == q);
+        if (m) {
+            if (key == q) val = v;
+        } else {
+            if (lane == cnt) {
+                key = q;
+                val = v;
+            }
+            ++cnt;
+        }
+    }
+};
+
+__global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow,
+                                                                float *__restrict__ cnewK, int64_t cn_stride, int32_t *__restrict__ slot_id,
+                                                                int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
+                                                                float *__restrict__ rowmin, int32_t *__restrict__ rownn,
+                                                                int32_t *__restrict__ merges, const float *__restrict__ Dtri,
+                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int sh[8];
+    __shared__ ward_state ls; // snapshot of the state at kernel entry
+    __shared__ int cm_slot_a[WB_K], cm_from[WB_K], cm_to[WB_K];
+    __shared__ int pk_a[WB_K], pk_b[WB_K], pk_sa[WB_K], pk_sb[WB_K], pk_sla[WB_K], pk_slb[WB_K], npk;
+    __shared__ float pk_v[WB_K];
+    const unsigned long long tf0 = wall_clock64();
+    {
+        constexpr int NW = (int)(sizeof(ward_state) / 4);
+        static_assert(NW <= 1024 && sizeof(ward_state) % 4 == 0, "snapshot by one pass");
+        if (threadIdx.x < NW) reinterpret_cast<int *>(&ls)[threadIdx.x] = reinterpret_cast<const int *>(st)[threadIdx.x];
+        if (threadIdx.x == 0) npk = 0;
+    }
+    __syncthreads();
+    if (ls.done) return;
+    const int nbp = ls.B.nb, t0 = ls.t, nlive0 = ls.nlive, target = ls.target;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- (1) validate: commit the longest prefix in which no pair of an earlier new cluster precedes the pick ----
+    int J = nbp;
+    for (int j = 1; j < nbp && J == nbp; ++j)
+        for (int i = 0; i < j; ++i) {
+            const unsigned long long k = ls.B.ckey[i];
+            if (k != ~0ull && __uint_as_float((unsigned)(k >> 32)) < ls.B.val[j]) {
+                J = j;
+                break;
+            }
+        }
+    const int t = t0 + J;
+    const bool fast = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // the preselection's assumption held
+    wb_map idm{-2, -1}, slm{-2, -1}; // id -> slot, slot -> id (wave 0 only)
+    int idcnt = 12;
+    if (wave == 0 && J > 0) {
+        // entries touched by the commits: the members (lanes 0..7), the last J live slots and their occupants (lanes 8..11)
+        if (lane < 2 * J) {
+            const int j = lane >> 1;
+            const int id = (lane & 1) ? ls.B.b[j] : ls.B.a[j];
+            const int sl = id_slot[id];
+            idm.key = id;
+            idm.val = sl;
+            slm.key = sl;
+            slm.val = id;
+        } else if (lane >= 8 && lane < 8 + J) {
+            const int sl = nlive0 - 1 - (lane - 8);
+            const int id = slot_id[sl];
+            slm.key = sl;
+            slm.val = id;
+            idm.key = id;
+            idm.val = sl;
+        }
+        for (int j = 0; j < J; ++j) {
+            const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
+            int slot_a = -1, slot_b = -1;
+            idm.get(a, slot_a);
+            idm.get(b, slot_b);
+            idm.set(c, slot_a, idcnt, lane); // the new cluster inherits a's slot
+            int dummy = 64;
+            slm.set(slot_a, c, dummy, lane);
+            slm.set(slot_b, -1, dummy, lane);
+            const int last = nlive0 - 1 - j; // keep live slots dense: the cluster in the last slot moves into b's slot
+            int from = -1, to = -1;
+            if (slot_b != last) {
+                int y = -1;
+                slm.get(last, y);
+                from = last;
+                to = slot_b;
+                slm.set(to, y, dummy, lane);
+                idm.set(y, to, idcnt, lane);
+                slm.set(last, -1, dummy, lane);
+            }
+            if (lane == 0) {
+                cm_slot_a[j] = slot_a;
+                cm_from[j] = from;
+                cm_to[j] = to;
+            }
+        }
+        if (idm.key >= 0) id_slot[idm.key] = idm.val;
+        if (slm.key >= 0) slot_id[slm.key] = slm.val;
+        if (lane < J) {
+            const int j = lane;
+            const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
+            const unsigned long long key = ls.B.ckey[j];
+            merges[2 * (t0 + j)] = a;
+            merges[2 * (t0 + j) + 1] = b;
+            asz[a] = 0;
+            asz[b] = 0;
+            asz[c] = ls.B.sa[j] + ls.B.sb[j];
+            rowmin[a] = ICL_MAXF;
+            rowmin[b] = ICL_MAXF;
+            rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
+            rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
+        }
+        if (fast && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
+            rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
+            rownn[ls.B.ov_row[lane]] = ls.B.ov_nn[lane];
+        }
+        if (J == nbp && lane < WB_R && ls.B.spec_done[lane] == ls.B.epoch && ls.B.spec_row[lane] >= 0) { // ... and by the spare workgroups
+            rowmin[ls.B.spec_row[lane]] = ls.B.spec_val[lane];
+            rownn[ls.B.spec_row[lane]] = ls.B.spec_nn[lane];
+        }
+        if (lane == 0) {
+            st->nlive = nlive0 - J;
+            st->t = t;
+            st->B.steps = ls.B.steps + 1;
+            st->B.commits = ls.B.commits + J;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;
+    if (wave != 0 || t >= target || !fast) {
+        // centroid images of the committed clusters: cnew_j into a's slot, THEN the compaction move (which may move it)
+        const int nthr = (t >= target || !fast) ? (int)blockDim.x : (int)blockDim.x - 64;
+        const int tid = (t >= target || !fast) ? (int)threadIdx.x : (int)threadIdx.x - 64;
+        for (int k = tid; k < d; k += nthr) {
+            for (int j = 0; j < J; ++j) {
+                const int slot_a = cm_slot_a[j], from = cm_from[j], to = cm_to[j];
+                const float cv = cnewK[j * cn_stride + k];
+                Crow[(int64_t)slot_a * d + k] = cv;
+                CT[ct4_off(k >> 2, S, slot_a) + (k & 3)] = cv;
+                if (to >= 0) {
+                    const float mv = Crow[(int64_t)from * d + k];
+                    Crow[(int64_t)to * d + k] = mv;
+                    CT[ct4_off(k >> 2, S, to) + (k & 3)] = mv;
+                }
+            }
+        }
+    } else {
+        // ---- (2) wave 0, fast path: candidates = rows just created (exact) + the preselected old-row pairs ----
+        // (uniform scalar code; every lane computes the same thing from the snapshot)
+        int crow[WB_K], cnn[WB_K];
+        float cval[WB_K];
+        bool cused[WB_K];
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j) {
+            crow[j] = -1;
+            cnn[j] = -1;
+            cval[j] = ICL_MAXF;
+            cused[j] = true;
+            if (j < J) {
+                const unsigned long long key = ls.B.ckey[j];
+                if (key != ~0ull) {
+                    const int x = (int)(key & 0xffffffffu);
+                    bool died = false; // its minimum partner may have been merged later in the same batch
+                    for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]);
+                    crow[j] = (int)(n + t0 + j);
+                    cnn[j] = died ? -2 : x;
+                    cval[j] = __uint_as_float((unsigned)(key >> 32));
+                    cused[j] = false;
+                }
+            }
+        }
+        const int pn = ls.B.pre_n;
+        int ip = 0, np = 0;
+        int mem[2 * WB_K];
+#pragma unroll
+        for (int z = 0; z < 2 * WB_K; ++z) mem[z] = -1;
+        int ra[WB_K], rb[WB_K], rsa[WB_K], rsb[WB_K];
+        float rv[WB_K];
+        bool stop = false;
+#pragma unroll
+        for (int q = 0; q < WB_K; ++q) {
+            ra[q] = rb[q] = -1;
+            rsa[q] = rsb[q] = 0;
+            rv[q] = 0.0f;
+            if (stop || t + np >= target) continue;
+            int bc = -1; // smallest remaining new-row candidate (rows ascending break ties)
+            float bcv = ICL_MAXF;
+            int bcr = 0x7fffffff;
+#pragma unroll
+            for (int z = 0; z < WB_K; ++z)
+                if (!cused[z] && (cval[z] < bcv || (cval[z] == bcv && crow[z] < bcr))) {
+                    bc = z;
+                    bcv = cval[z];
+                    bcr = crow[z];
+                }
+            const bool have_p = ip < pn;
+            const float pv = have_p ? ls.B.pre_val[ip < WB_K ? ip : 0] : ICL_MAXF;
+            int a_, b_, sa_ = 0, sb_ = 0;
+            float v_;
+            if (bc >= 0 && have_p && bcv < pv) { // strict: old rows win ties (smaller row index)
+                int bnn = -1;
+#pragma unroll
+                for (int z = 0; z < WB_K; ++z)
+                    if (z == bc) {
+                        bnn = cnn[z];
+                        cused[z] = true;
+                        sa_ = ls.B.sa[z] + ls.B.sb[z];
+                    }
+                if (bnn == -2) { // a stale bound: anything from here on is unknown
+                    stop = true;
+                    continue;
+                }
+                a_ = bcr;
+                b_ = bnn;
+                v_ = bcv;
+                sb_ = -1; // partner's size: looked up below
+            } else if (have_p) {
+                // a new-row pair beyond the preselection's coverage cannot be ordered: only preselected pairs from here
+                a_ = ls.B.pre_row[ip];
+                b_ = ls.B.pre_nn[ip];
+                v_ = pv;
+                sa_ = ls.B.pre_sa[ip];
+                sb_ = ls.B.pre_sb[ip];
+                ++ip;
+            } else {
+                stop = true;
+                continue;
+            }
+            bool clash = false;
+#pragma unroll
+            for (int z = 0; z < 2 * WB_K; ++z) clash |= (mem[z] == a_) | (mem[z] == b_);
+            if (clash) {
+                stop = true;
+                continue;
+            }
+            // partner of a new row: another new row of this batch, or an old untouched cluster
+            if (sb_ < 0) {
+                sb_ = 0;
+#pragma unroll
+                for (int z = 0; z < WB_K; ++z)
+                    if (z < J && b_ == (int)(n + t0 + z)) sb_ = ls.B.sa[z] + ls.B.sb[z];
+                if (sb_ == 0) sb_ = asz[b_];
+            }
+#pragma unroll
+            for (int z = 0; z < WB_K; ++z)
+                if (z == np) {
+                    ra[z] = a_;
+                    rb[z] = b_;
+                    rsa[z] = sa_;
+                    rsb[z] = sb_;
+                    rv[z] = v_;
+                    mem[2 * z] = a_;
+                    mem[2 * z + 1] = b_;
+                }
+            ++np;
+        }
+        // slots: entries touched by this kernel come from the lane map, the rest from memory
+#pragma unroll
+        for (int z = 0; z < WB_K; ++z) {
+            if (z < np) {
+                int sla = -1, slb = -1;
+                if (!idm.get(ra[z], sla)) sla = id_slot[ra[z]];
+                if (!idm.get(rb[z], slb)) slb = id_slot[rb[z]];
+                if (lane == 0) {
+                    pk_a[z] = ra[z];
+                    pk_b[z] = rb[z];
+                    pk_sa[z] = rsa[z];
+                    pk_sb[z] = rsb[z];
+                    pk_sla[z] = sla;
+                    pk_slb[z] = slb;
+                    pk_v[z] = rv[z];
+                }
+            }
+        }
+        if (lane == 0) npk = np;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->B.dbg[4] += wall_clock64() - tf0;
+    if (t >= target) {
+        if (threadIdx.x == 0) st->B.nb = 0; // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
+        return;
+    }
+    if (npk == 0) {
+        // slow path (first step, truncated batch, or nothing usable): ONE pick by the lazy selection over all rows
+        const int64_t nvec = (n + t + 3) >> 2;
+        float bv;
+        int bi;
+        for (;;) {
+            bv = ICL_MAXF;
+            bi = -1;
+            for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t q = q0 + (int64_t)j * blockDim.x;
+                    v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t q = q0 + (int64_t)j * blockDim.x;
+                    const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (e[i] < bv) {
+                            bv = e[i];
+                            bi = (int)(q * 4 + i);
+                        }
+                }
+            }
+            block_argmin(bv, bi, sv, si);
+            if (bi < 0) break;
+            if (threadIdx.x == 0) sh[1] = asz[rownn[bi]] > 0 ? 0 : 1;
+            __syncthreads();
+            const int dirty = sh[1];
+            __syncthreads();
+            if (!dirty) break;
+            float rv;
+            int ri;
+            scan_row(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, rv, ri);
+            block_argmin(rv, ri, sv, si);
+            if (threadIdx.x == 0) {
+                rowmin[bi] = rv;
+                rownn[bi] = ri;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            st->B.slow = ls.B.slow + 1;
+            if (bi < 0) {
+                st->done = 1; // clustering.go:222-225 "No more clusters to merge."
+                st->B.nb = 0;
+            } else {
+                const int nn = rownn[bi];
+                pk_a[0] = bi;
+                pk_b[0] = nn;
+                pk_v[0] = bv;
+                pk_sa[0] = asz[bi];
+                pk_sb[0] = asz[nn];
+                pk_sla[0] = id_slot[bi];
+                pk_slb[0] = id_slot[nn];
+                npk = 1;
+            }
+        }
+        __syncthreads();
+        if (npk == 0) return;
+    }
+    // ---- (3) the batch record and its merged centroids ----
+    const int np = npk;
+    if (threadIdx.x < WB_K) {
+        const int j = threadIdx.x;
+        if (j < np) {
+            st->B.a[j] = pk_a[j];
+            st->B.b[j] = pk_b[j];
+            st->B.sa[j] = pk_sa[j];
+            st->B.sb[j] = pk_sb[j];
+            st->B.val[j] = pk_v[j];
+            st->B.ckey[j] = ~0ull;
+            rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
+        }
+        if (j == 0) {
+            st->B.nb = np;
+            st->B.epoch = ls.B.epoch + 1;
+            st->B.pre_n = 0;
+            st->B.ov_n = 0;
+            st->B.pre_for_nb = -1;
+        }
+    }
+    for (int j = 0; j < np; ++j) {
+        // MergeClusters centroid (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb) / float(sa+sb), each op rounded
+        const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
+        const float *ra = Crow + (int64_t)pk_sla[j] * d, *rb = Crow + (int64_t)pk_slb[j] * d;
+        float *cn = cnewK + j * cn_stride;
+        for (int k = threadIdx.x; k < d; k += blockDim.x) {
+            const float pa = fa * ra[k];
+            const float pb = fb * rb[k];
+            const float sm = pa + pb;
+            cn[k] = sm / fs;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -901,12 +1947,13 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
             return icl_fail(ctx, ICL_ERR_NOMEM, "ward workspace: hipMalloc(%s, %lld x %zu B) failed: %s", #field, \
                             (long long)(count), sizeof(type), hipGetErrorString(e__));                          \
     } while (0)
-        const int64_t ngrp = upd_groups((int)dd) + UPD_PAD_G; // the update kernel streams whole stages and prefetches past the end
+        const int64_t ngrp = std::max<int64_t>(upd_groups((int)dd) + UPD_PAD_G, wb_groups((int)dd) + WB_PAD_G); // whole stages + prefetch slack
         WS_ALLOC(CT, float, 4 * ngrp * w->S);
         ICL_HIP(ctx, hipMemsetAsync(w->CT, 0, (size_t)(4 * ngrp * w->S) * sizeof(float), ctx->stream));
         WS_ALLOC(Crow, float, dd * w->S);
-        WS_ALLOC(cnew, float, 4 * ngrp);
-        ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(4 * ngrp) * sizeof(float), ctx->stream));
+        w->cn_stride = 4 * std::max<int64_t>(ngrp, wb_groups((int)dd) + WB_PAD_G);
+        WS_ALLOC(cnew, float, WB_K * w->cn_stride);
+        ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(WB_K * w->cn_stride) * sizeof(float), ctx->stream));
         WS_ALLOC(slot_id, int32_t, w->S);
         WS_ALLOC(id_slot, int32_t, w->M);
         WS_ALLOC(asz, int32_t, w->M);
@@ -1198,13 +2245,96 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     };
     const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
     constexpr int GRAPH_STEPS = 64;
+    static const bool batch_env = [] {
+        const char *e = getenv("ICL_WARD_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    const bool batched = !lw && batch_env;
+    ward_state hst;
+    if (batched) {
+        // Batched exact mode: each step attempts up to WB_K independent merges, so the number of steps is data
+        // dependent (between T/WB_K and T).  Steps are enqueued in chunks of GRAPH_STEPS; the state is read back after
+        // each chunk, one chunk behind the launches so the queue never drains.
+        const int dqb = (int)wb_groups(d);
+        const size_t wb_lds_bytes = (size_t)2 * WB_SG * 64 * 16 + (size_t)WB_K * (dqb + WB_PAD_G) * 16;
+        if (wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+        static bool wb_attr = false;
+        if (!wb_attr) {
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); // + the preselection's static arrays
+            wb_attr = true;
+        }
+        const unsigned wb_blocks = (unsigned)(w->S / 64) + 2 + WB_R; // + spare re-minimisers + preselection + virtual slots
+        auto finish_b = [&]() {
+            hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
+                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st);
+        };
+        auto update_b = [&]() {
+            hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->cnew,
+                               w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+        };
+        auto step_b = [&](bool prof) {
+            if (prof) {
+                // n_live is only known on the device: the profile records launches, bytes are attributed by the caller
+                icl_prof_scope ps(ctx, ICL_K_UPDATE, 0.0, 0.0);
+                update_b();
+            } else {
+                update_b();
+            }
+            finish_b();
+        };
+        finish_b(); // first batch: one pick by the plain lazy selection
+        const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != 2)) {
+            if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
+            w->graph_exec = nullptr;
+            hipGraph_t graph = nullptr;
+            ICL_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            for (int g = 0; g < GRAPH_STEPS; ++g) step_b(false);
+            ICL_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
+            hipError_t ge = hipGraphInstantiate(&w->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
+            w->graph_max_size = max_size;
+            w->graph_lw = 2;
+        }
+        ward_state *hpin = nullptr; // two pinned snapshots
+        ICL_HIP(ctx, hipHostMalloc((void **)&hpin, 2 * sizeof(ward_state), hipHostMallocDefault));
+        hipEvent_t evs[2];
+        ICL_HIP(ctx, hipEventCreateWithFlags(&evs[0], hipEventDisableTiming));
+        ICL_HIP(ctx, hipEventCreateWithFlags(&evs[1], hipEventDisableTiming));
+        auto finished = [&](const ward_state &h) { return h.done || h.t >= T; };
+        int rc_b = ICL_OK;
+        int64_t chunk = 0;
+        const int64_t max_chunks = T / GRAPH_STEPS + 3; // every step commits at least one merge until the end
+        bool fin = T == 0;
+        while (!fin && chunk < max_chunks) {
+            if (use_graph) {
+                if (hipGraphLaunch(w->graph_exec, ctx->stream) != hipSuccess) { rc_b = ICL_ERR_HIP; break; }
+            } else {
+                for (int g = 0; g < GRAPH_STEPS; ++g) step_b(prof_update);
+            }
+            const int sl = (int)(chunk & 1);
+            if (hipMemcpyAsync(&hpin[sl], w->st, sizeof(ward_state), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipEventRecord(evs[sl], ctx->stream) != hipSuccess) { rc_b = ICL_ERR_HIP; break; }
+            if (chunk >= 1) { // look at the chunk before this one while this one runs
+                if (hipEventSynchronize(evs[sl ^ 1]) != hipSuccess) { rc_b = ICL_ERR_HIP; break; }
+                fin = finished(hpin[sl ^ 1]);
+            }
+            ++chunk;
+        }
+        if (rc_b == ICL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc_b = ICL_ERR_HIP;
+        (void)hipEventDestroy(evs[0]);
+        (void)hipEventDestroy(evs[1]);
+        (void)hipHostFree(hpin);
+        if (rc_b != ICL_OK) return icl_fail(ctx, ICL_ERR_HIP, "batched merge loop: %s", hipGetErrorString(hipGetLastError()));
+    } else {
     hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff,
                        max_size, w->st); // merge 0 has no update in front of it
     finish();
     if (prof_update || T < 2 * GRAPH_STEPS) {
         for (int64_t t = 0; t < T; ++t) enqueue_step(t, prof_update);
     } else {
-        if (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != lw) {
+        if (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (int)lw) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -1215,17 +2345,23 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = lw;
+            w->graph_lw = (int)lw;
         }
         for (int64_t t = 0; t < T; t += GRAPH_STEPS) ICL_HIP(ctx, hipGraphLaunch(w->graph_exec, ctx->stream));
+    }
     }
     ICL_HIP(ctx, hipGetLastError());
     ICL_HIP(ctx, hipEventRecord(e2, ctx->stream));
 
-    ward_state hst;
     ICL_HIP(ctx, hipMemcpyAsync(&hst, w->st, sizeof hst, hipMemcpyDeviceToHost, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t nmerge = hst.t;
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d\n", hst.t, hst.B.steps, hst.B.commits, hst.B.slow);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select %.1f total %.1f\n",
+                hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,
+                hst.B.dbg[3] * 0.01 / hst.B.steps, hst.B.dbg[4] * 0.01 / hst.B.steps, hst.B.dbg[5] * 0.01 / hst.B.steps);
     std::vector<int32_t> pairs((size_t)(2 * nmerge));
     if (nmerge) {
         ICL_HIP(ctx, hipMemcpyAsync(pairs.data(), w->merges, (size_t)(2 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));
