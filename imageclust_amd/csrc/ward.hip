@@ -23,7 +23,15 @@ int icl_dist_mfma_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, float
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-#define WB_K 4 /* merges attempted per batched step */
+// in-kernel stage timers (100 MHz wall clock) for tuning: compile with -DICL_WARD_TIMERS, print with ICL_WARD_STATS=1
+#ifdef ICL_WARD_TIMERS
+#define WB_TIMER(stmt) stmt
+#else
+#define WB_TIMER(stmt)
+#endif
+#ifndef WB_K
+#define WB_K 8 /* merges attempted per batched step */
+#endif
 #define WB_R 24 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
@@ -35,12 +43,13 @@ struct ward_batch_state {
     int32_t ov_n, ov_pad;                         // rows re-minimised under the "batch commits" assumption
     int32_t ov_row[8], ov_nn[8];
     float ov_val[8];
-    int32_t epoch, spec_pad[3];                   // speculative row re-minimisation by the spare workgroups
+    int32_t dirty_n, dirty_slot[2 * WB_K];        // slots whose CT4 column (k-groups >= 2 stages) still has to be re-made from Crow
+    int32_t epoch, spec_pad[2];                   // speculative row re-minimisation by the spare workgroups
     int32_t spec_row[WB_R], spec_nn[WB_R], spec_done[WB_R];
     float spec_val[WB_R];
     int32_t commits, steps, slow, pad;            // statistics
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
-    unsigned long long dbg[8], dbg_t0;
+    unsigned long long dbg[8], dbg_t0, dbg2[3];
 };
 
 struct ward_state {
@@ -434,10 +443,12 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->B.pre_for_nb = -1;
         st->B.commits = st->B.steps = st->B.slow = 0;
         st->B.epoch = 1;
+        st->B.dirty_n = 0;
         st->B.ov_n = 0;
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = ~0ull;
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
+        for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
     }
 }
 
@@ -913,7 +924,9 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
 #define WB_P 6
 #define WB_GP 4
 #define WB_SG (WB_P * WB_GP)          /* k-groups per stage */
-#define WB_THREADS (64 * (WB_P + WB_K)) /* WB_K chain waves (one per tentative cluster) + WB_P producers */
+#define WB_KC 4                        /* chain waves per workgroup: one per SIMD */
+#define WB_NH (WB_K / WB_KC)            /* workgroups sharing a 64-slot block, each with WB_KC of the batch's chains */
+#define WB_THREADS (64 * (WB_P + WB_KC)) /* WB_KC chain waves (one per tentative cluster) + WB_P producers */
 #define WB_PAD_G (4 * WB_SG)
 static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 1) / WB_SG * WB_SG; }
 
@@ -1112,18 +1125,20 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
     for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
     // ---- one pass: per-lane two smallest (value,row) keys; the batch's own members are skipped (dead if it commits)
     unsigned long long k1 = ~0ull, k2 = ~0ull;
-    {
+    const int nsw = nwave < 64 / (WB_WTOP + 1) ? nwave : 64 / (WB_WTOP + 1); // scanning waves: their streams fit one wave
+    const int nst = nsw * 64;
+    if (wave < nsw) {
         const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32
-        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)nst) {
             float4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const int64_t q = q0 + (int64_t)j * nst;
                 v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const int64_t q = q0 + (int64_t)j * nst;
                 const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1148,7 +1163,7 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
         }
     }
     // ---- per wave: pop the WB_WTOP smallest, then a sentinel = lower bound of the rest of the wave
-    {
+    if (wave < nsw) {
         unsigned long long head = k1;
         int stg = 0; // 0: head = k1, 1: head = k2, 2: head = sentinel(k2)
         bool ended = false;
@@ -1173,7 +1188,7 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
     int nn = -1, nsz = 0, rsz = 0;
     bool nn_alive = false;
     if (wave == 0) {
-        if (lane < nwave * (WB_WTOP + 1)) key = wstream[lane];
+        if (lane < nsw * (WB_WTOP + 1)) key = wstream[lane];
         if (key != ~0ull && !(key & 1ull)) {
             const int r = (int)((key & 0xffffffffull) >> 1);
             nn = rownn[r];
@@ -1182,7 +1197,7 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
             nn_alive = nsz > 0;
         }
     }
-    if (threadIdx.x == 0) st->B.dbg[7] += wall_clock64() - st->B.dbg_t0;
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[7] += wall_clock64() - st->B.dbg_t0;)
     int npick = 0, nov = 0, nresc = 0;
     const int epoch = st->B.epoch;
     int spl_row = -1, spl_nn = -1, spl_n = -1; // lane l: result of spare workgroup l (loaded on first use)
@@ -1318,13 +1333,14 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
         st->B.pre_n = npick;
         st->B.ov_n = nov;
         st->B.pre_for_nb = nb;
-        st->B.dbg[6] += nresc;
+        WB_TIMER(st->B.dbg[6] += nresc;)
     }
 }
 
 // update for a batch: rows of up to WB_K tentative clusters in one pass over the centroids.
-__global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, int dqp, int64_t S, const float *__restrict__ CT,
-                                                                      const float *__restrict__ cnewK, int64_t cn_stride,
+__global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+                                                                      const float *__restrict__ Crow, const float *__restrict__ cnewK,
+                                                                      int64_t cn_stride,
                                                                       const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
                                                                       const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
@@ -1343,18 +1359,22 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
         int *sh = si + 16;
-        const unsigned long long t0 = wall_clock64();
-        if (threadIdx.x == 0) st->B.dbg_t0 = t0;
+        WB_TIMER(const unsigned long long t0 = wall_clock64();)
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
         ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
-        if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long tm0 = wall_clock64();
-    const bool virt = blockIdx.x == WB_R + 1; // "virtual slots": lane i = tentative cluster c_i, column = its new centroid
-    const int64_t mblk = (int64_t)blockIdx.x - (WB_R + 2);
+    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
+    // blocks WB_R+1 .. WB_R+WB_NH: "virtual slots" (lane i = tentative cluster c_i, column = its new centroid)
+    const bool virt = blockIdx.x <= WB_R + WB_NH;
+    const int64_t mb = (int64_t)blockIdx.x - (WB_R + 1 + WB_NH);
+    const int64_t mblk = virt ? 0 : mb / WB_NH;
+    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)(mb % WB_NH); // which WB_KC chains this workgroup runs
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
     int pa[WB_K], pb[WB_K], psc[WB_K];
 #pragma unroll
     for (int j = 0; j < WB_K; ++j) {
@@ -1367,17 +1387,30 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
     const unsigned voff = virt ? (unsigned)((lane < WB_K ? lane : 0) * cn_stride * 4) : (unsigned)slot * 16u;
     const int64_t row_bytes = virt ? 16 : S * 16;
-    const int pj = wave - WB_K; // producer index (waves WB_K..), chain index = wave (waves 0..WB_K-1)
-    const bool producer = wave >= WB_K;
+    const int pj = wave - WB_KC; // producer index (waves WB_KC..), chain index = half*WB_KC + wave (waves 0..WB_KC-1)
+    const bool producer = wave >= WB_KC;
     struct xq { float4 g0, g1, g2, g3; }; // WB_GP == 4 k-groups of one slot, kept in named registers
     static_assert(WB_GP == 4, "xq holds four groups");
+    // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
+    // streams its centroid from the row-major copy instead and re-makes the column on the way
+    bool dirty_lane = false;
+    const int dq_real = d >> 2;
     auto load = [&](int stage) {
-        const char *rb = ctb + (int64_t)(stage * WB_SG + pj * WB_GP) * row_bytes + voff;
+        const int g0 = stage * WB_SG + pj * WB_GP;
+        const char *rb = ctb + (int64_t)g0 * row_bytes + voff;
+        const char *r0 = rb, *r1 = rb + row_bytes, *r2 = rb + 2 * row_bytes, *r3 = rb + 3 * row_bytes;
+        if (dirty_lane) {
+            const char *cr = reinterpret_cast<const char *>(Crow) + ((int64_t)slot * d + (int64_t)g0 * 4) * 4;
+            if (g0 + 0 < dq_real) r0 = cr;
+            if (g0 + 1 < dq_real) r1 = cr + 16;
+            if (g0 + 2 < dq_real) r2 = cr + 32;
+            if (g0 + 3 < dq_real) r3 = cr + 48;
+        }
         xq v;
-        v.g0 = *reinterpret_cast<const float4 *>(rb);
-        v.g1 = *reinterpret_cast<const float4 *>(rb + row_bytes);
-        v.g2 = *reinterpret_cast<const float4 *>(rb + 2 * row_bytes);
-        v.g3 = *reinterpret_cast<const float4 *>(rb + 3 * row_bytes);
+        v.g0 = *reinterpret_cast<const float4 *>(r0);
+        v.g1 = *reinterpret_cast<const float4 *>(r1);
+        v.g2 = *reinterpret_cast<const float4 *>(r2);
+        v.g3 = *reinterpret_cast<const float4 *>(r3);
         return v;
     };
     xq va = {}, vb = {}, vc = {};
@@ -1385,7 +1418,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         va = load(0);
         vb = load(1);
     }
-    if (done || nb <= 0) return;
+    if (done || nb <= half * WB_KC) return;
     if (!virt && mblk * 64 >= nlive) return;
     // which rows does this lane's cluster take part in?
     int x, sx;
@@ -1414,23 +1447,48 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             }
         }
     }
-    if (!__any(okmask != 0)) return;
+    okmask >>= half * WB_KC; // this workgroup's chains
+    const int nd = virt ? 0 : dirty_n0;
+    for (int z = 0; z < nd; ++z) dirty_lane |= __shfl(dirty_s0, z, 64) == (int)slot;
+    if (!__any((okmask & ((1u << WB_KC) - 1u)) != 0)) {
+        // nothing to compute here, but a stale column must not outlive this step's dirty list
+        if (half == 0) {
+            unsigned long long dm = __ballot(dirty_lane);
+            while (dm) {
+                const int l = __ffsll((long long)dm) - 1;
+                dm &= dm - 1;
+                const int64_t sl = mblk * 64 + l;
+                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WB_THREADS)
+                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
+            }
+        }
+        return;
+    }
     float4 *cn4 = wb_lds + 2 * WB_SG * 64;
     const int cnl = dqp + WB_PAD_G; // float4s per centroid image in LDS
-    for (int j = 0; j < nb; ++j)
-        for (int g = threadIdx.x; g < cnl; g += WB_THREADS) cn4[j * cnl + g] = reinterpret_cast<const float4 *>(cnewK + j * cn_stride)[g];
+    const int nch = nb - half * WB_KC < WB_KC ? nb - half * WB_KC : WB_KC; // chains run here
+    for (int j = 0; j < nch; ++j)
+        for (int g = threadIdx.x; g < cnl; g += WB_THREADS)
+            cn4[j * cnl + g] = reinterpret_cast<const float4 *>(cnewK + (half * WB_KC + j) * cn_stride)[g];
     __syncthreads();
     float s = 0.0f;
     // producers only move x (global -> LDS); every chain wave squares its own differences: the 8 VALU instructions per
     // 4 k (2 pk_sub, 2 pk_mul, 4 dependent adds) issue in about the time the 4 dependent adds take anyway, and the ring
     // is written once per column instead of once per (column, chain) -- ds_write_b128 is the expensive LDS operation
-    auto produce = [&](const xq &v, int buf) {
+    auto produce = [&](const xq &v, int buf, int stage) {
         ring[buf][pj * WB_GP + 0][lane] = v.g0;
         ring[buf][pj * WB_GP + 1][lane] = v.g1;
         ring[buf][pj * WB_GP + 2][lane] = v.g2;
         ring[buf][pj * WB_GP + 3][lane] = v.g3;
+        if (dirty_lane && stage >= 2) { // re-make the column (both workgroups of a slot block write the same values)
+            const int g0 = stage * WB_SG + pj * WB_GP;
+            if (g0 + 0 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 0, S, slot)) = v.g0;
+            if (g0 + 1 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 1, S, slot)) = v.g1;
+            if (g0 + 2 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 2, S, slot)) = v.g2;
+            if (g0 + 3 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 3, S, slot)) = v.g3;
+        }
     };
-    const bool chain = wave < nb;
+    const bool chain = wave < nch;
     const float4 *cnj = cn4 + (chain ? wave : 0) * cnl;
     auto consume = [&](int buf, int stage) {
         const float4 *cs = cnj + stage * WB_SG;
@@ -1459,14 +1517,14 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     for (int i = 0; i < nstage; i += 3) {
         if (producer) {
             vc = load(i + 2);
-            produce(va, i & 1);
+            produce(va, i & 1, i);
         }
         __syncthreads();
         if (chain) consume(i & 1, i);
         if (i + 1 < nstage) {
             if (producer) {
                 va = load(i + 3);
-                produce(vb, (i + 1) & 1);
+                produce(vb, (i + 1) & 1, i + 1);
             }
             __syncthreads();
             if (chain) consume((i + 1) & 1, i + 1);
@@ -1474,7 +1532,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         if (i + 2 < nstage) {
             if (producer) {
                 vb = load(i + 4);
-                produce(vc, i & 1);
+                produce(vc, i & 1, i + 2);
             }
             __syncthreads();
             if (chain) consume(i & 1, i + 2);
@@ -1482,9 +1540,9 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     }
     if (!chain) return;
     {
-        const int j = wave;
+        const int j = half * WB_KC + wave;
         unsigned long long key = ~0ull;
-        if ((okmask >> j) & 1u) {
+        if ((okmask >> wave) & 1u) {
             int sc = psc[0];
 #pragma unroll
             for (int q = 1; q < WB_K; ++q)
@@ -1502,8 +1560,8 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             key = o < key ? o : key;
         }
         if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
-        if (lane == 0 && j == 0 && mblk == 0) st->B.dbg[1] += wall_clock64() - tm0;
-        if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;
+        WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
+        WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
 }
 
@@ -1538,7 +1596,8 @@ struct wb_map { // a tiny associative array spread over the lanes of a wave
     }
 };
 
-__global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow,
+#define WB_FIN_THREADS 512
+__global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow,
                                                                 float *__restrict__ cnewK, int64_t cn_stride, int32_t *__restrict__ slot_id,
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
                                                                 float *__restrict__ rowmin, int32_t *__restrict__ rownn,
@@ -1552,10 +1611,10 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
     __shared__ int cm_slot_a[WB_K], cm_from[WB_K], cm_to[WB_K];
     __shared__ int pk_a[WB_K], pk_b[WB_K], pk_sa[WB_K], pk_sb[WB_K], pk_sla[WB_K], pk_slb[WB_K], npk;
     __shared__ float pk_v[WB_K];
-    const unsigned long long tf0 = wall_clock64();
+    WB_TIMER(const unsigned long long tf0 = wall_clock64();)
     {
         constexpr int NW = (int)(sizeof(ward_state) / 4);
-        static_assert(NW <= 1024 && sizeof(ward_state) % 4 == 0, "snapshot by one pass");
+        static_assert(NW <= WB_FIN_THREADS && sizeof(ward_state) % 4 == 0, "snapshot by one pass");
         if (threadIdx.x < NW) reinterpret_cast<int *>(&ls)[threadIdx.x] = reinterpret_cast<const int *>(st)[threadIdx.x];
         if (threadIdx.x == 0) npk = 0;
     }
@@ -1564,21 +1623,31 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
     const int nbp = ls.B.nb, t0 = ls.t, nlive0 = ls.nlive, target = ls.target;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- (1) validate: commit the longest prefix in which no pair of an earlier new cluster precedes the pick ----
+    // (wave 0: lane i*WB_K+j tests "a pair of c_i precedes p_j")
+    static_assert(WB_K * WB_K <= 64, "one lane per (i, j)");
     int J = nbp;
-    for (int j = 1; j < nbp && J == nbp; ++j)
-        for (int i = 0; i < j; ++i) {
-            const unsigned long long k = ls.B.ckey[i];
-            if (k != ~0ull && __uint_as_float((unsigned)(k >> 32)) < ls.B.val[j]) {
-                J = j;
-                break;
-            }
+    if (wave == 0) {
+        const int vi = lane / WB_K, vj = lane % WB_K;
+        bool bad = false;
+        if (vi < vj && vj < nbp && lane < WB_K * WB_K) {
+            const unsigned long long k = ls.B.ckey[vi];
+            bad = k != ~0ull && __uint_as_float((unsigned)(k >> 32)) < ls.B.val[vj];
         }
-    const int t = t0 + J;
-    const bool fast = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // the preselection's assumption held
+        const unsigned long long bm = __ballot(bad);
+        unsigned long long colm = 0; // lanes with vj == 1
+        for (int i2 = 0; i2 < WB_K; ++i2) colm |= 1ull << (i2 * WB_K + 1);
+        for (int j2 = 1; j2 < WB_K; ++j2) {
+            if (j2 < J && (bm & (colm << (j2 - 1)))) J = j2;
+        }
+        if (lane == 0) sh[0] = J;
+    }
     wb_map idm{-2, -1}, slm{-2, -1}; // id -> slot, slot -> id (wave 0 only)
-    int idcnt = 12;
+    int rec = -1, frm = -1;          // wave 0: lane r = destination slot of write record r; lane j = source slot of move j
+    const bool full0 = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // wave 0's view (its J is final)
+    int idcnt = 3 * WB_K;
+    static_assert(4 * WB_K <= 64, "lane map capacity");
     if (wave == 0 && J > 0) {
-        // entries touched by the commits: the members (lanes 0..7), the last J live slots and their occupants (lanes 8..11)
+        // entries touched by the commits: the members (lanes 0..2K-1), the last J live slots and their occupants (lanes 2K..3K-1)
         if (lane < 2 * J) {
             const int j = lane >> 1;
             const int id = (lane & 1) ? ls.B.b[j] : ls.B.a[j];
@@ -1587,8 +1656,8 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
             idm.val = sl;
             slm.key = sl;
             slm.val = id;
-        } else if (lane >= 8 && lane < 8 + J) {
-            const int sl = nlive0 - 1 - (lane - 8);
+        } else if (lane >= 2 * WB_K && lane < 2 * WB_K + J) {
+            const int sl = nlive0 - 1 - (lane - 2 * WB_K);
             const int id = slot_id[sl];
             slm.key = sl;
             slm.val = id;
@@ -1620,9 +1689,23 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
                 cm_from[j] = from;
                 cm_to[j] = to;
             }
+            if (lane == 2 * j) rec = slot_a; // write records in program order: lane 2j = slot_a_j, lane 2j+1 = to_j
+            if (lane == 2 * j + 1) rec = to;
+            if (lane == j) frm = from;
         }
         if (idm.key >= 0) id_slot[idm.key] = idm.val;
         if (slm.key >= 0) slot_id[slm.key] = slm.val;
+        {
+            // slots whose CT4 column the update kernel has to re-make: the last write record of every touched slot
+            bool live = rec >= 0 && (d & 3) == 0;
+            for (int r2 = 1; r2 < 2 * WB_K; ++r2) {
+                const int o = __shfl_down(rec, r2, 64);
+                if (lane + r2 < 2 * WB_K && o == rec) live = false;
+            }
+            const unsigned long long lm = __ballot(live);
+            if (live) st->B.dirty_slot[__popcll(lm & ((1ull << lane) - 1ull))] = rec;
+            if (lane == 0) st->B.dirty_n = __popcll(lm);
+        }
         if (lane < J) {
             const int j = lane;
             const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
@@ -1637,7 +1720,7 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
             rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
             rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
         }
-        if (fast && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
+        if (full0 && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
             rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
             rownn[ls.B.ov_row[lane]] = ls.B.ov_nn[lane];
         }
@@ -1647,31 +1730,234 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
         }
         if (lane == 0) {
             st->nlive = nlive0 - J;
-            st->t = t;
+            st->t = t0 + J;
             st->B.steps = ls.B.steps + 1;
             st->B.commits = ls.B.commits + J;
         }
     }
+    // ---- express path (the common case), decided by wave 0: the whole batch committed, the preselection's
+    // assumption held and no pair of a row just created can precede the last preselected pair -> the next batch is the
+    // preselected list as it stands (its pairs are pairwise disjoint and prefix-closed by construction)
+    if (wave == 0) {
+        int express = 0;
+        const int t1 = t0 + J;
+        const int pn0 = ls.B.pre_n;
+        if (full0 && t1 < target && pn0 > 0 && (d & 3) == 0 && (d >> 2) <= WB_FIN_THREADS) {
+            float cmin = ICL_MAXF;
+            if (lane < J) {
+                const unsigned long long key = ls.B.ckey[lane];
+                if (key != ~0ull) cmin = __uint_as_float((unsigned)(key >> 32));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, off, 64));
+            if (cmin >= ls.B.pre_val[pn0 - 1]) {
+                express = 1;
+                const int np = pn0 < target - t1 ? pn0 : target - t1;
+                int myid = -1;
+                if (lane < np) myid = ls.B.pre_row[lane];
+                else if (lane >= WB_K && lane < WB_K + np) myid = ls.B.pre_nn[lane - WB_K];
+                int gs = myid >= 0 ? id_slot[myid] : -1;
+                for (int m = 0; m < 4 * WB_K; ++m) { // entries touched by this kernel come from the lane map
+                    const int mk = __shfl(idm.key, m, 64), mv = __shfl(idm.val, m, 64);
+                    if (mk >= 0 && mk == myid) gs = mv;
+                }
+                if (lane < np) {
+                    const int j = lane;
+                    pk_sa[j] = ls.B.pre_sa[j];
+                    pk_sb[j] = ls.B.pre_sb[j];
+                    pk_sla[j] = gs;
+                    st->B.a[j] = ls.B.pre_row[j];
+                    st->B.b[j] = ls.B.pre_nn[j];
+                    st->B.sa[j] = ls.B.pre_sa[j];
+                    st->B.sb[j] = ls.B.pre_sb[j];
+                    st->B.val[j] = ls.B.pre_val[j];
+                    st->B.ckey[j] = ~0ull;
+                    rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
+                } else if (lane >= WB_K && lane < WB_K + np)
+                    pk_slb[lane - WB_K] = gs;
+                // does anything read a slot that this batch's commits write?  (rare: then values are forwarded)
+                bool need = false;
+                for (int r = 0; r < 2 * WB_K; ++r) {
+                    const int o = __shfl(rec, r, 64);
+                    if (o >= 0 && o == gs) need = true;                      // a pick member of the next batch
+                    if (o >= 0 && o == frm && lane < WB_K && r <= 2 * lane) need = true; // a move's source
+                }
+                const bool fwd = __ballot(need) != 0;
+                if (lane == 0) {
+                    sh[3] = fwd ? 1 : 0;
+                    npk = np;
+                    st->B.nb = np;
+                    st->B.epoch = ls.B.epoch + 1;
+                    st->B.pre_n = 0;
+                    st->B.ov_n = 0;
+                    st->B.pre_for_nb = -1;
+                    WB_TIMER(st->B.dbg2[0] += wall_clock64() - tf0;)
+                }
+            }
+        }
+        if (lane == 0) sh[2] = express;
+    }
+    if (wave == 0 && J == 0 && lane == 0) st->B.dirty_n = 0;
     __syncthreads();
-    if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;
+    J = sh[0];
+    const int t = t0 + J;
+    const bool fast = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // the preselection's assumption held
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;)
+    if (sh[2]) {
+        // one data phase, one k-group per thread: centroid images of the committed clusters (cnew_j into a's slot, THEN
+        // the compaction move, which may move it) and the merged centroids of the next batch (clustering.go:37-40);
+        // values written here are forwarded in registers, so there is no barrier and one round of loads
+        const int np = npk;
+        const int g = threadIdx.x;
+        if (g < (d >> 2)) {
+            int rs[2 * WB_K]; // write records in program order: 2j = slot_a_j, 2j+1 = to_j (-1: none)
+            int cfr[WB_K];
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                rs[2 * j] = j < J ? cm_slot_a[j] : -1;
+                rs[2 * j + 1] = j < J ? cm_to[j] : -1;
+                cfr[j] = j < J ? cm_from[j] : -1;
+            }
+            int sla[WB_K], slb[WB_K];
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                sla[j] = j < np ? pk_sla[j] : -1;
+                slb[j] = j < np ? pk_slb[j] : -1;
+            }
+            float4 wv[2 * WB_K], av[WB_K], bv[WB_K];
+            const float4 z4 = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) { // every load up front: they are independent
+                wv[2 * j] = j < J ? reinterpret_cast<const float4 *>(cnewK + j * cn_stride)[g] : z4;
+                wv[2 * j + 1] = cfr[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)cfr[j] * d)[g] : z4;
+                av[j] = sla[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)sla[j] * d)[g] : z4;
+                bv[j] = slb[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)slb[j] * d)[g] : z4;
+            }
+            if (sh[3]) {
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) { // a move whose source was written earlier in this batch takes that value
+                if (cfr[j] >= 0) {
+#pragma unroll
+                    for (int r = 0; r <= 2 * j; ++r)
+                        if (rs[r] == cfr[j]) wv[2 * j + 1] = wv[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) { // pick members that live in a slot written by this batch: its final content
+#pragma unroll
+                for (int r = 0; r < 2 * WB_K; ++r) {
+                    if (rs[r] >= 0 && rs[r] == sla[j]) av[j] = wv[r];
+                    if (rs[r] >= 0 && rs[r] == slb[j]) bv[j] = wv[r];
+                }
+            }
+            }
+#pragma unroll
+            for (int r = 0; r < 2 * WB_K; ++r) {
+                bool dd = rs[r] < 0; // skipped when a later record overwrites the same slot
+#pragma unroll
+                for (int r2 = r + 1; r2 < 2 * WB_K; ++r2) dd |= rs[r2] == rs[r];
+                if (!dd) {
+                    reinterpret_cast<float4 *>(Crow + (int64_t)rs[r] * d)[g] = wv[r];
+                    if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, rs[r])) = wv[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                if (j < np) {
+                    const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
+                    float4 o;
+                    { const float pa = fa * av[j].x; const float pb = fb * bv[j].x; const float sm = pa + pb; o.x = sm / fs; }
+                    { const float pa = fa * av[j].y; const float pb = fb * bv[j].y; const float sm = pa + pb; o.y = sm / fs; }
+                    { const float pa = fa * av[j].z; const float pb = fb * bv[j].z; const float sm = pa + pb; o.z = sm / fs; }
+                    { const float pa = fa * av[j].w; const float pb = fb * bv[j].w; const float sm = pa + pb; o.w = sm / fs; }
+                    reinterpret_cast<float4 *>(cnewK + j * cn_stride)[g] = o;
+                }
+            }
+        }
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
+        return;
+    }
     if (wave != 0 || t >= target || !fast) {
         // centroid images of the committed clusters: cnew_j into a's slot, THEN the compaction move (which may move it)
         const int nthr = (t >= target || !fast) ? (int)blockDim.x : (int)blockDim.x - 64;
         const int tid = (t >= target || !fast) ? (int)threadIdx.x : (int)threadIdx.x - 64;
+        int csa[WB_K], cfr[WB_K], cto[WB_K];
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j) {
+            csa[j] = j < J ? cm_slot_a[j] : -1;
+            cfr[j] = j < J ? cm_from[j] : -1;
+            cto[j] = j < J ? cm_to[j] : -1;
+        }
+        // write records in program order: 2j = (slot_a_j <- cnew_j), 2j+1 = (to_j <- content of from_j at that time);
+        // a record is skipped when a later one overwrites the same slot
+        bool wdead[2 * WB_K];
+#pragma unroll
+        for (int r = 0; r < 2 * WB_K; ++r) {
+            const int sr = (r & 1) ? cto[r >> 1] : csa[r >> 1];
+            bool dd = sr < 0;
+#pragma unroll
+            for (int r2 = r + 1; r2 < 2 * WB_K; ++r2) dd |= ((r2 & 1) ? cto[r2 >> 1] : csa[r2 >> 1]) == sr;
+            wdead[r] = dd;
+        }
+        if ((d & 3) == 0) { // whole k-groups: 16-byte accesses
+            const int dq = d >> 2;
+            for (int g = tid; g < dq; g += nthr) {
+                float4 wv[2 * WB_K];
+#pragma unroll
+                for (int j = 0; j < WB_K; ++j) { // every load up front: they are independent
+                    wv[2 * j] = j < J ? reinterpret_cast<const float4 *>(cnewK + j * cn_stride)[g] : make_float4(0, 0, 0, 0);
+                    wv[2 * j + 1] = cfr[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)cfr[j] * d)[g] : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < WB_K; ++j) { // a move whose source was written earlier in this batch takes that value
+                    if (cfr[j] >= 0) {
+#pragma unroll
+                        for (int r = 0; r <= 2 * j; ++r) {
+                            const int sr = (r & 1) ? cto[r >> 1] : csa[r >> 1];
+                            if (sr == cfr[j]) wv[2 * j + 1] = wv[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2 * WB_K; ++r) {
+                    if (!wdead[r]) {
+                        const int sr = (r & 1) ? cto[r >> 1] : csa[r >> 1];
+                        reinterpret_cast<float4 *>(Crow + (int64_t)sr * d)[g] = wv[r];
+                        // the scattered CT4 column is re-made by the update kernel's workgroup that owns the slot
+                        // (dirty list); only the two stages it loads before it has read the state are written here
+                        if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sr)) = wv[r];
+                    }
+                }
+            }
+        } else
         for (int k = tid; k < d; k += nthr) {
-            for (int j = 0; j < J; ++j) {
-                const int slot_a = cm_slot_a[j], from = cm_from[j], to = cm_to[j];
-                const float cv = cnewK[j * cn_stride + k];
-                Crow[(int64_t)slot_a * d + k] = cv;
-                CT[ct4_off(k >> 2, S, slot_a) + (k & 3)] = cv;
-                if (to >= 0) {
-                    const float mv = Crow[(int64_t)from * d + k];
-                    Crow[(int64_t)to * d + k] = mv;
-                    CT[ct4_off(k >> 2, S, to) + (k & 3)] = mv;
+            float wv[2 * WB_K];
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) { // every load up front: they are independent
+                wv[2 * j] = j < J ? cnewK[j * cn_stride + k] : 0.0f;
+                wv[2 * j + 1] = cfr[j] >= 0 ? Crow[(int64_t)cfr[j] * d + k] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) { // a move whose source was written earlier in this batch takes that value
+                if (cfr[j] >= 0) {
+#pragma unroll
+                    for (int r = 0; r <= 2 * j; ++r) {
+                        const int sr = (r & 1) ? cto[r >> 1] : csa[r >> 1];
+                        if (sr == cfr[j]) wv[2 * j + 1] = wv[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2 * WB_K; ++r) {
+                if (!wdead[r]) {
+                    const int sr = (r & 1) ? cto[r >> 1] : csa[r >> 1];
+                    Crow[(int64_t)sr * d + k] = wv[r];
+                    CT[ct4_off(k >> 2, S, sr) + (k & 3)] = wv[r];
                 }
             }
         }
     } else {
+        {
         // ---- (2) wave 0, fast path: candidates = rows just created (exact) + the preselected old-row pairs ----
         // (uniform scalar code; every lane computes the same thing from the snapshot)
         int crow[WB_K], cnn[WB_K];
@@ -1781,28 +2067,37 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
                 }
             ++np;
         }
-        // slots: entries touched by this kernel come from the lane map, the rest from memory
+        // slots: one parallel load (lane z: a_z, lane WB_K+z: b_z); entries touched by this kernel come from the lane map
+        int myid = -1;
+#pragma unroll
+        for (int z = 0; z < WB_K; ++z) {
+            if (lane == z && z < np) myid = ra[z];
+            if (lane == WB_K + z && z < np) myid = rb[z];
+        }
+        int gs = myid >= 0 ? id_slot[myid] : -1;
 #pragma unroll
         for (int z = 0; z < WB_K; ++z) {
             if (z < np) {
-                int sla = -1, slb = -1;
-                if (!idm.get(ra[z], sla)) sla = id_slot[ra[z]];
-                if (!idm.get(rb[z], slb)) slb = id_slot[rb[z]];
+                int v = -1;
+                if (idm.get(ra[z], v) && lane == z) gs = v;
+                if (idm.get(rb[z], v) && lane == WB_K + z) gs = v;
                 if (lane == 0) {
                     pk_a[z] = ra[z];
                     pk_b[z] = rb[z];
                     pk_sa[z] = rsa[z];
                     pk_sb[z] = rsb[z];
-                    pk_sla[z] = sla;
-                    pk_slb[z] = slb;
                     pk_v[z] = rv[z];
                 }
             }
         }
+        if (lane < WB_K) pk_sla[lane] = gs;
+        else if (lane < 2 * WB_K) pk_slb[lane - WB_K] = gs;
+        WB_TIMER(if (lane == 0) st->B.dbg2[0] += wall_clock64() - tf0;)
         if (lane == 0) npk = np;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) st->B.dbg[4] += wall_clock64() - tf0;
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[4] += wall_clock64() - tf0;)
     if (t >= target) {
         if (threadIdx.x == 0) st->B.nb = 0; // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
         return;
@@ -1892,20 +2187,60 @@ __global__ __launch_bounds__(1024) void ward_finish_batch_kernel(int64_t n, int 
             st->B.pre_for_nb = -1;
         }
     }
-    for (int j = 0; j < np; ++j) {
+    {
         // MergeClusters centroid (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb) / float(sa+sb), each op rounded
-        const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
-        const float *ra = Crow + (int64_t)pk_sla[j] * d, *rb = Crow + (int64_t)pk_slb[j] * d;
-        float *cn = cnewK + j * cn_stride;
+        int sla[WB_K], slb[WB_K];
+        float fa[WB_K], fb[WB_K], fs[WB_K];
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j) {
+            sla[j] = j < np ? pk_sla[j] : 0;
+            slb[j] = j < np ? pk_slb[j] : 0;
+            fa[j] = (float)pk_sa[j < np ? j : 0];
+            fb[j] = (float)pk_sb[j < np ? j : 0];
+            fs[j] = (float)(pk_sa[j < np ? j : 0] + pk_sb[j < np ? j : 0]);
+        }
+        if ((d & 3) == 0) {
+            const int dq = d >> 2;
+            for (int g = threadIdx.x; g < dq; g += blockDim.x) {
+                float4 av[WB_K], bv[WB_K];
+#pragma unroll
+                for (int j = 0; j < WB_K; ++j) {
+                    av[j] = j < np ? reinterpret_cast<const float4 *>(Crow + (int64_t)sla[j] * d)[g] : make_float4(0, 0, 0, 0);
+                    bv[j] = j < np ? reinterpret_cast<const float4 *>(Crow + (int64_t)slb[j] * d)[g] : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < WB_K; ++j) {
+                    if (j < np) {
+                        float4 o;
+                        { const float pa = fa[j] * av[j].x; const float pb = fb[j] * bv[j].x; const float sm = pa + pb; o.x = sm / fs[j]; }
+                        { const float pa = fa[j] * av[j].y; const float pb = fb[j] * bv[j].y; const float sm = pa + pb; o.y = sm / fs[j]; }
+                        { const float pa = fa[j] * av[j].z; const float pb = fb[j] * bv[j].z; const float sm = pa + pb; o.z = sm / fs[j]; }
+                        { const float pa = fa[j] * av[j].w; const float pb = fb[j] * bv[j].w; const float sm = pa + pb; o.w = sm / fs[j]; }
+                        reinterpret_cast<float4 *>(cnewK + j * cn_stride)[g] = o;
+                    }
+                }
+            }
+        } else
         for (int k = threadIdx.x; k < d; k += blockDim.x) {
-            const float pa = fa * ra[k];
-            const float pb = fb * rb[k];
-            const float sm = pa + pb;
-            cn[k] = sm / fs;
+            float av[WB_K], bv[WB_K];
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                av[j] = j < np ? Crow[(int64_t)sla[j] * d + k] : 0.0f;
+                bv[j] = j < np ? Crow[(int64_t)slb[j] * d + k] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                if (j < np) {
+                    const float pa = fa[j] * av[j];
+                    const float pb = fb[j] * bv[j];
+                    const float sm = pa + pb;
+                    cnewK[j * cn_stride + k] = sm / fs[j];
+                }
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2256,20 +2591,20 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // dependent (between T/WB_K and T).  Steps are enqueued in chunks of GRAPH_STEPS; the state is read back after
         // each chunk, one chunk behind the launches so the queue never drains.
         const int dqb = (int)wb_groups(d);
-        const size_t wb_lds_bytes = (size_t)2 * WB_SG * 64 * 16 + (size_t)WB_K * (dqb + WB_PAD_G) * 16;
+        const size_t wb_lds_bytes = (size_t)2 * WB_SG * 64 * 16 + (size_t)WB_KC * (dqb + WB_PAD_G) * 16;
         if (wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
         static bool wb_attr = false;
         if (!wb_attr) {
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); // + the preselection's static arrays
             wb_attr = true;
         }
-        const unsigned wb_blocks = (unsigned)(w->S / 64) + 2 + WB_R; // + spare re-minimisers + preselection + virtual slots
+        const unsigned wb_blocks = (unsigned)(w->S / 64) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
         auto finish_b = [&]() {
-            hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
+            hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st);
         };
         auto update_b = [&]() {
-            hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->cnew,
+            hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow, w->cnew,
                                w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
         };
         auto step_b = [&](bool prof) {
@@ -2358,10 +2693,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const int64_t nmerge = hst.t;
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d\n", hst.t, hst.B.steps, hst.B.commits, hst.B.slow);
+#ifdef ICL_WARD_TIMERS
     if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select %.1f total %.1f\n",
+        fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
                 hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,
-                hst.B.dbg[3] * 0.01 / hst.B.steps, hst.B.dbg[4] * 0.01 / hst.B.steps, hst.B.dbg[5] * 0.01 / hst.B.steps);
+                hst.B.dbg[3] * 0.01 / hst.B.steps, hst.B.dbg2[0] * 0.01 / hst.B.steps, hst.B.dbg[4] * 0.01 / hst.B.steps, hst.B.dbg[5] * 0.01 / hst.B.steps);
+#endif
     std::vector<int32_t> pairs((size_t)(2 * nmerge));
     if (nmerge) {
         ICL_HIP(ctx, hipMemcpyAsync(pairs.data(), w->merges, (size_t)(2 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -148,6 +148,59 @@ def test_cluster_exact_ties_and_duplicates(ctx, seed):
         same_as_oracle(ctx, E, mn, mx)
 
 
+# ---- inputs aimed at the batched merge loop (ward.hip: up to WB_K tentative merges per step) ----------------------
+def test_batch_dependent_chain(ctx):
+    """A hub that absorbs one spoke after another (spokes on orthogonal axes, growing radii): almost every merge
+    involves the cluster created by the merge before it, so every batch but its first pick must be rolled back by
+    the validation in the finish kernel.  Plus 1-D points with growing gaps."""
+    d = 48
+    E = np.zeros((d + 1, d), np.float32)
+    for i in range(d):
+        E[i + 1, i] = 1.1 ** i
+    r = O.cluster(E, 1, d + 1, want_log=True)
+    L = r["log"][:, 2:4].astype(int)
+    assert sum(1 for t in range(1, len(L)) if d + t in L[t]) >= len(L) - 2  # the input does what it is meant to
+    for mn, mx in [(1, d + 1), (1, 12), (2, 5)]:
+        same_as_oracle(ctx, E, mn, mx)
+    x = np.cumsum(1.07 ** np.arange(150)).astype(np.float32)[:, None]
+    for mn, mx in [(1, 150), (2, 9), (1, 3)]:
+        same_as_oracle(ctx, x, mn, mx)
+
+
+def test_batch_new_clusters_merge_with_each_other(ctx):
+    """Tight quadruples (pairs of pairs): clusters created in one batch are each other's nearest neighbours, which
+    exercises the virtual-slot distances and new-row picks."""
+    rng = np.random.default_rng(11)
+    base = (rng.standard_normal((60, 12)) * 50).astype(np.float32)
+    off = np.zeros((4, 12), np.float32)
+    off[1, 0] = 0.01
+    off[2, 0] = 0.05
+    off[3, 0] = 0.061
+    E = (base[:, None, :] + off[None, :, :]).reshape(-1, 12)
+    E = E[rng.permutation(len(E))]
+    for mn, mx in [(1, 240), (2, 4), (3, 8), (1, 2)]:
+        same_as_oracle(ctx, E, mn, mx)
+
+
+@pytest.mark.parametrize("n,d,mn,mx", [(100, 4096, 2, 10), (90, 2052, 1, 7), (700, 6, 1, 9), (600, 5, 2, 40)])
+def test_batch_paths_wide_and_odd_dims(ctx, n, d, mn, mx):
+    # d > 2048 and d % 4 != 0 take the general (non-express) finish path; small d with many points makes batches full
+    same_as_oracle(ctx, mog(n, d, n + d), mn, mx)
+
+
+def test_batch_heavy_ties_at_scale(ctx):
+    rng = np.random.default_rng(3)
+    E = rng.integers(0, 3, (600, 5)).astype(np.float32)
+    for mn, mx in [(1, 600), (2, 12)]:
+        same_as_oracle(ctx, E, mn, mx)
+
+
+def test_batch_target_reached_inside_a_batch(ctx):
+    # few merges needed (k close to n): the loop must stop after exactly n-k merges, mid-batch
+    for n, mn, mx in [(100, 1, 1), (100, 1, 2), (101, 1, 2), (37, 1, 3), (64, 5, 64)]:
+        same_as_oracle(ctx, mog(n, 16, n), mn, mx)
+
+
 def test_cluster_all_identical_points(ctx):
     same_as_oracle(ctx, np.ones((37, 5), np.float32), 2, 4)
 
