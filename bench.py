@@ -213,17 +213,27 @@ def main():
                      "all_conv_achieved": round((c128["flops"] + c64["flops"]) / max(c128["ms"] + c64["ms"], 1e-9) / 1e9, 2),
                      "embed_frac_of_bf16_peak": round(n_local * FLOP_PER_IMAGE / max(result.get("embed_ms", 0), 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
                      "measured": "HIP events around every launch during the timed steps"}
+        # dominant kernel by total GPU time (rocprofv3 stats in profiles/): the 128x128 implicit-GEMM conv (MFMA bound);
+        # the Ward update kernel (HBM bound: one pass over the live centroids per launch) is reported beside it
         roof = conv_roof
+        ward_roof = None
         if upd and upd["launches"]:
+            ws = ctx.last_ward_stats()
             gbs = upd["bytes"] / max(upd["ms"], 1e-9) / 1e6  # GB/s
-            roof = {"bound": "hbm", "kernel": "ward_update_exact_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd, "launches": upd["launches"],
-                    "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
-                    "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),
-                    "algorithmic_unit": "4*n_live*D + 4*n_live bytes per merge (SURVEY.md 8d), n_live = clusters alive at that merge",
-                    "note": "dominant kernel by total GPU time (rocprofv3 stats in profiles/); small-n launches are bound by the D dependent "
-                            "fp32 adds of the in-order sum (6.4 us), not by HBM",
-                    "measured": "HIP events around every launch in one extra untimed eager pass over the same E (the timed steps replay a hipGraph)"}
+            exact = args.update == "exact"
+            ward_roof = {"bound": "hbm", "kernel": "ward_update_batch_kernel" if exact else "ward_update_lw_kernel",
+                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if not exact else None, "launches": upd["launches"],
+                         "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
+                         "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),
+                         "merges_per_working_launch": round(ws["merges"] / max(ws["steps"], 1), 2),
+                         "algorithmic_unit": "4*n_live*D bytes (one pass over the live centroids) + 4*n_live per new row, per LAUNCH; a launch "
+                                             "computes the rows of up to 8 independent merges from that one pass (SURVEY.md 8d quotes "
+                                             "4*n_live*D per merge)",
+                         "note": "bound by the D dependent fp32 adds of each in-order sum (one wave per merge row and 64 clusters), "
+                                 "not by HBM; launches after the last merge of a 64-step chunk are empty",
+                         "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
+                                     "(the timed steps replay a hipGraph)"}
         out = {
             "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +248,7 @@ def main():
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
             "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
             "roofline": roof,
-            "roofline_conv": conv_roof,
+            "roofline_ward_update": ward_roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("icl_prof_reset", _int, [_vp]),
     ("icl_prof_query", _int, [_vp, _int, _pd, _pi64, _pd, _pd]),
     ("icl_last_stage_ms", _int, [_vp, _pd, _pd, _pd]),
+    ("icl_last_ward_stats", _int, [_vp, _vp, _vp, _vp, _vp]),
     ("icl_version", C.c_char_p, []),
 ]
 
@@ -185,6 +186,11 @@ class Context:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         check(self.h, self.L.icl_last_stage_ms(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(embed_ms=a.value, dist_ms=b.value, merge_ms=c.value)
+
+    def last_ward_stats(self):
+        v = [_i64() for _ in range(4)]
+        check(self.h, self.L.icl_last_ward_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(merges=v[0].value, steps=v[1].value, single_pick_steps=v[2].value, sum_live=v[3].value)
 
     # -- model / embed --------------------------------------------------------------------------------
     def load_synthetic(self, seed=1):

@@ -48,6 +48,7 @@ struct ward_batch_state {
     int32_t spec_row[WB_R], spec_nn[WB_R], spec_done[WB_R];
     float spec_val[WB_R];
     int32_t commits, steps, slow, pad;            // statistics
+    unsigned long long sum_live, sum_live_nb;     // sum over steps of live clusters (x picks)
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long dbg[8], dbg_t0, dbg2[3];
 };
@@ -442,6 +443,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->B.pre_n = 0;
         st->B.pre_for_nb = -1;
         st->B.commits = st->B.steps = st->B.slow = 0;
+        st->B.sum_live = st->B.sum_live_nb = 0;
         st->B.epoch = 1;
         st->B.dirty_n = 0;
         st->B.ov_n = 0;
@@ -1787,6 +1789,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                     sh[3] = fwd ? 1 : 0;
                     npk = np;
                     st->B.nb = np;
+                    st->B.sum_live = ls.B.sum_live + (unsigned long long)(nlive0 - J);
+                    st->B.sum_live_nb = ls.B.sum_live_nb + (unsigned long long)(nlive0 - J) * np;
                     st->B.epoch = ls.B.epoch + 1;
                     st->B.pre_n = 0;
                     st->B.ov_n = 0;
@@ -2181,6 +2185,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         }
         if (j == 0) {
             st->B.nb = np;
+            st->B.sum_live = ls.B.sum_live + (unsigned long long)(nlive0 - J);
+            st->B.sum_live_nb = ls.B.sum_live_nb + (unsigned long long)(nlive0 - J) * np;
             st->B.epoch = ls.B.epoch + 1;
             st->B.pre_n = 0;
             st->B.ov_n = 0;
@@ -2699,6 +2705,21 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                 hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,
                 hst.B.dbg[3] * 0.01 / hst.B.steps, hst.B.dbg2[0] * 0.01 / hst.B.steps, hst.B.dbg[4] * 0.01 / hst.B.steps, hst.B.dbg[5] * 0.01 / hst.B.steps);
 #endif
+    ctx->ward_stats[0] = nmerge;
+    if (batched) {
+        // steps = launches that carried work: the first finish picks without committing, every later one commits >= 1
+        ctx->ward_stats[1] = hst.B.steps;
+        ctx->ward_stats[2] = hst.B.slow;
+        ctx->ward_stats[3] = (int64_t)hst.B.sum_live;
+        if (prof_update) { // algorithmic work of the launches just profiled (n_live is only known on the device)
+            ctx->prof[ICL_K_UPDATE].flops += 3.0 * d * (double)hst.B.sum_live_nb;
+            ctx->prof[ICL_K_UPDATE].bytes += 4.0 * d * (double)hst.B.sum_live + 4.0 * (double)hst.B.sum_live_nb;
+        }
+    } else {
+        ctx->ward_stats[1] = nmerge;
+        ctx->ward_stats[2] = nmerge;
+        ctx->ward_stats[3] = (int64_t)nmerge * n - (int64_t)nmerge * (nmerge + 1) / 2;
+    }
     std::vector<int32_t> pairs((size_t)(2 * nmerge));
     if (nmerge) {
         ICL_HIP(ctx, hipMemcpyAsync(pairs.data(), w->merges, (size_t)(2 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2780,6 +2801,16 @@ extern "C" int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, con
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(buf);
     if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "icl_merge_centroid: %s", hipGetErrorString(e));
+    return ICL_OK;
+}
+
+extern "C" int icl_last_ward_stats(icl_ctx *ctx, int64_t *merges, int64_t *steps, int64_t *single_pick_steps, int64_t *sum_live)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    if (merges) *merges = ctx->ward_stats[0];
+    if (steps) *steps = ctx->ward_stats[1];
+    if (single_pick_steps) *single_pick_steps = ctx->ward_stats[2];
+    if (sum_live) *sum_live = ctx->ward_stats[3];
     return ICL_OK;
 }
 

@@ -147,6 +147,10 @@ int icl_prof_reset(icl_ctx *ctx);
 int icl_prof_query(icl_ctx *ctx, int kclass, double *ms, int64_t *launches, double *flops, double *bytes);
 /* Stage wall times (ms, HIP events on the context stream) of the last embed / cluster call. */
 int icl_last_stage_ms(icl_ctx *ctx, double *embed_ms, double *dist_ms, double *merge_ms);
+/* Shape of the last icl_cluster[_dev] merge loop: merges done, update-kernel launches that carried work ("steps"; the
+ * exact mode attempts several independent merges per launch, ICL_UPDATE_LW one), steps that fell back to a single
+ * pick, and the sum over steps of the live cluster count (x 4*D bytes = centroid bytes streamed by the update kernel). */
+int icl_last_ward_stats(icl_ctx *ctx, int64_t *merges, int64_t *steps, int64_t *single_pick_steps, int64_t *sum_live);
 
 const char *icl_version(void);
 
