@@ -258,7 +258,7 @@ static constexpr size_t conv_lds_bytes(int nstages = 2)
 // ------------------------------------------------------------------------------------------------------------
 #define STEM_K 192
 #define STEM_ROWK 24         /* k slots per filter row (21 used) */
-#define STEM_PW 116          /* patch row stride in bytes: 37 pixels * 3 = 111, + slack for the padded slots, 4-aligned */
+#define STEM_PW 120          /* patch row stride in bytes: 3 (alignment) + 37 pixels * 3 = 114, + slack for the padded slots, 4-aligned */
 #define STEM_PH 21
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restrict__ img, const conv_args p)
@@ -289,15 +289,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
                                                  (lptr_t)(smem + j * WST + (wid * 16 + i * 8) * CV_ROWB), 16, 0, 0);
             }
     }
-    // input patch: rows iy = ty*16-3 .. +20, byte columns (tx*32-3)*3 .. ; zero outside the image
+    // input patch: rows iy = ty*16-3 .. +20, byte columns (tx*32-3)*3 .. ; zero outside the image.  The first byte
+    // column is 3 mod 4 for every tile (tx*96 - 9), rows are 672 bytes and images 150528 bytes apart, so the patch is
+    // fetched as ALIGNED dwords from byte column bx0-3 on (a dword is entirely inside or outside the image) and the
+    // chunk addresses below carry the 3-byte offset
     {
         const uint8_t *ib = img + b * (int64_t)ICL_IMG_BYTES;
-        const int iy0 = ty * 16 - 3, bx0 = (tx * 32 - 3) * 3;
-        for (int i = tid; i < PATCH; i += 256) {
-            const int pr = i / STEM_PW, pc = i - pr * STEM_PW;
-            const int iy = iy0 + pr, bx = bx0 + pc;
-            const bool ok = pr < STEM_PH && (unsigned)iy < 224u && (unsigned)bx < 672u;
-            patch[i] = ok ? ib[iy * 672 + bx] : (uint8_t)0;
+        const int iy0 = ty * 16 - 3, bx0 = (tx * 32 - 3) * 3 - 3;
+        constexpr int RW = STEM_PW / 4; // dwords per patch row
+        static_assert(STEM_PW % 4 == 0, "patch rows are whole dwords");
+        uint32_t *p32 = reinterpret_cast<uint32_t *>(patch);
+        constexpr int NDW = STEM_PH * RW + 4;
+        uint32_t v[(NDW + 255) / 256];
+#pragma unroll
+        for (int q = 0; q < (NDW + 255) / 256; ++q) {
+            const int i = tid + q * 256;
+            const int pr = i / RW, pc = i - pr * RW;
+            const int iy = iy0 + pr, bx = bx0 + pc * 4;
+            const bool ok = i < NDW && pr < STEM_PH && (unsigned)iy < 224u && (unsigned)bx < 672u;
+            v[q] = ok ? *reinterpret_cast<const uint32_t *>(ib + iy * 672 + bx) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < (NDW + 255) / 256; ++q) {
+            const int i = tid + q * 256;
+            if (i < NDW) p32[i] = v[q];
         }
     }
     __syncthreads();
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
             const int oyl = row >> 4, oxl = row & 15;
             elem v[T::KE];
             if (kh < 7) {
-                const int addr = (oyl * 2 + kh) * STEM_PW + oxl * 6 + r0; // even: 0 or 2 mod 4
+                const int addr = (oyl * 2 + kh) * STEM_PW + oxl * 6 + r0 + 3; // + 3: the patch starts 3 bytes left of the tile
                 const uint32_t *w32 = reinterpret_cast<const uint32_t *>(patch + (addr & ~3));
                 const uint32_t d0 = w32[0], d1 = w32[1], d2 = w32[2];
                 const int sh = addr & 3;

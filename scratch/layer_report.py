@@ -15,8 +15,8 @@ for s in range(4):
         ho=h//stride
         layers.append(('s%d.b%d.c1'%(s+1,bl),cin,mid,1,ho))
         layers.append(('s%d.b%d.c2'%(s+1,bl),mid,mid,3,ho))
-        if bl==0: layers.append(('s%d.b%d.ds'%(s+1,bl),cin,cout,1,ho))
-        layers.append(('s%d.b%d.c3'%(s+1,bl),mid,cout,1,ho))
+        # block 0: the downsample conv is fused into c3 (dual-operand K axis = mid + cin)
+        layers.append(('s%d.b%d.c3'%(s+1,bl),mid + (cin if bl==0 else 0),cout,1,ho))
         cin=cout;h=ho
 convs=[e for e in batch if 'conv_igemm' in e[2]]
 tot=0;totf=0;agg={}
