@@ -43,9 +43,32 @@ struct conv_args {
 // accumulators (lane = pixel, 4 consecutive channels per register quad) -> fp32 LDS tile [pixel][channel] -> one
 // 16-byte channel chunk per lane, so residual reads and output stores are whole contiguous rows; a lane's chunk column
 // is fixed, so it needs only its own KE scale/shift values.  Callers must have finished reading the staged tiles.
+// residual chunks of one lane for both 64-row halves of a tile (conv_epilogue's access pattern); EARLY kernels issue
+// these loads before the K loop so their latency is hidden behind it
+template <typename T, int BN>
+struct conv_resid {
+    static constexpr int NPASS = 64 / (256 / (BN / T::KE));
+    uint4 v[2][NPASS];
+};
+template <typename T, int BN>
+__device__ __forceinline__ void conv_resid_load(const conv_args &p, conv_resid<T, BN> &r, int64_t m0, int n0, int tid)
+{
+    typedef typename T::elem elem;
+    constexpr int CPR = BN / T::KE, RPP = 256 / CPR, NPASS = 64 / RPP;
+    const elem *Rg = (const elem *)p.R;
+    const int nl = (tid % CPR) * T::KE;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int64_t m = m0 + half * 64 + tid / CPR + i * RPP;
+            r.v[half][i] = (Rg && m < p.M) ? *reinterpret_cast<const uint4 *>(Rg + m * p.Cout + n0 + nl) : make_uint4(0, 0, 0, 0);
+        }
+}
+
 template <typename T, int BN, bool TILE2D = false>
 __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char *smem, f32x16 (&acc)[BN / 64][2], int64_t m0, int n0,
-                                              int tid, int wm, int wn, int fr, int fh)
+                                              int tid, int wm, int wn, int fr, int fh, const conv_resid<T, BN> *pre = nullptr)
 {
     // TILE2D (stem): tile row r is pixel (r/16, r%16) of an 8x16 patch whose top-left output pixel is m0
     auto row_m = [&](int ml) -> int64_t { return TILE2D ? m0 + (int64_t)(ml >> 4) * p.Wo + (ml & 15) : m0 + ml; };
@@ -73,7 +96,10 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     for (int half = 0; half < 2; ++half) {
         // all residual loads of the lane for this half are issued before any arithmetic
         uint4 rv[NPASS];
-        if (Rg) {
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) rv[i] = pre->v[half][i];
+        } else if (Rg) {
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
                 const int64_t m = row_m(half * 64 + tid / CPR + i * RPP);
@@ -128,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     }
 }
 
-template <typename T, int BN, bool DUAL = false>
+template <typename T, int BN, bool DUAL = false, int NST = 2, bool EARLY = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 {
     typedef typename T::elem elem;
@@ -161,11 +187,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         const int row = wid * (CV_BM / 4) + i * 8 + prow;
         const int64_t m = m0 + row;
         xok[i] = m < p.M;
-        const int64_t mm = xok[i] ? m : 0;
-        const int ox = (int)(mm % p.Wo);
-        const int64_t t = mm / p.Wo;
-        const int oy = (int)(t % p.Ho);
-        const int b = (int)(t / p.Ho);
+        // 32-bit index math (launch_conv checks M < 2^31): 64-bit divisions cost ~100 instructions each, and tiles
+        // with few k-steps are bound by instruction issue
+        const unsigned mm = xok[i] ? (unsigned)m : 0u;
+        const unsigned t = mm / (unsigned)p.Wo;
+        const int ox = (int)(mm - t * (unsigned)p.Wo);
+        const int b = (int)(t / (unsigned)p.Ho);
+        const int oy = (int)(t - (unsigned)b * (unsigned)p.Ho);
         xiy[i] = oy * p.stride - p.pad;
         xix[i] = ox * p.stride - p.pad;
         xbase[i] = (((int64_t)b * p.H + xiy[i]) * p.W + xix[i]) * p.Cin;
@@ -225,18 +253,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
     };
 
     const int nk = p.K / T::BK;
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of stage 0 have landed ...
-    __syncthreads();                                  // ... and so have everybody else's
+    constexpr int OPS = WI + XI; // vector-memory operations one wave issues per stage (vmcnt counts them in order)
     const int fr = lane & 31, fh = lane >> 5;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) stage(cur ^ 1); // async: lands while this step's MFMAs run
-        const unsigned char *wsm = smem + cur * STAGE;
-        conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // next stage landed (this wave's pieces)
-        __syncthreads();                                  // all reads of `cur` done; all pieces of the next stage visible
+    static_assert(!EARLY || NST == 2, "EARLY uses the two-stage ring");
+    if constexpr (EARLY) {
+        // Few k-steps per tile: memory latency (~2 us) dwarfs a k-step's MFMAs, so the tile time is the number of
+        // load round trips on its critical path.  Everything that can be requested at once is: the residual chunks of
+        // the epilogue first, then BOTH stages; a stage buffer is refilled as soon as its step's MFMAs are done
+        // (a second barrier per k-step), so two k-steps stay in flight.
+        conv_resid<T, BN> res;
+        conv_resid_load<T, BN>(p, res, m0, n0, tid);
+        stage(0);
+        if (nk > 1) stage(1);
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory"); // stage ks landed, ks+1 may be in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned char *wsm = smem + (ks & 1) * STAGE;
+            conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
+            if (ks + 2 < nk) {
+                __syncthreads(); // everybody has read buffer ks&1
+                stage(ks & 1);
+            }
+        }
+        __syncthreads(); // the epilogue reuses the staging buffers
+        conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, &res);
+        return;
     }
+    // NST-stage ring, NST-1 k-steps of LDS-DMA in flight
+    static_assert(NST >= 2 && NST <= 4 && (NST - 2) * OPS < 64, "counted vmcnt waits");
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nk) stage(s0);
+    for (int ks = 0; ks < nk; ++ks) {
+        // stage ks must have landed; the (up to NST-2) stages issued after it may stay in flight
+        const int later = (ks + NST - 2 < nk - 1 ? ks + NST - 2 : nk - 1) - ks;
+        if (NST >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+        else if (NST >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // everybody's pieces of stage ks are visible; all reads of stage ks-1 are done
+        if (ks + NST - 1 < nk) stage((ks + NST - 1) % NST); // into the buffer read at step ks-1
+        const unsigned char *wsm = smem + (ks % NST) * STAGE;
+        conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
+    }
+    __syncthreads(); // the epilogue reuses the staging buffers
     conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh);
 }
 
@@ -733,32 +793,63 @@ static int ensure_ws(icl_ctx *ctx, int batch, int prec)
     return ICL_OK;
 }
 
+template <typename T, int BN, bool DUAL, int NST, bool EARLY = false>
+static void launch_conv_variant(icl_ctx *ctx, conv_args &a, int nst_lds)
+{
+    static bool attr_done = false; // one flag per instantiation: opt in to > 64 KiB of dynamic LDS
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, BN, DUAL, NST, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)conv_lds_bytes<BN>(NST));
+        attr_done = true;
+    }
+    a.gy = a.Cout / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, DUAL, NST, EARLY>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<BN>(nst_lds), ctx->stream,
+                       a);
+}
+
+// Tile / pipeline choice per layer (B=256 shapes of ResNet50, measured with scratch/layer_report.py):
+//  * K-heavy layers (3x3, K >= 1024) are MFMA bound: 128x128 tile, 2 stages (64 KB LDS, 2 workgroups per CU);
+//  * layers with few k-steps per tile are bound by the bytes a CU keeps in flight: 128x64 tile with a 3-stage ring
+//    (72 KB LDS, still 2 workgroups per CU, 2 k-steps in flight each).
+static int conv_mode_env()
+{
+    static const int v = [] {
+        const char *e = getenv("ICL_CONV_MODE");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
 template <typename T>
 static int launch_conv_t(icl_ctx *ctx, conv_args a)
 {
-    static bool attr_done = false;
-    if (!attr_done) { // opt in to > 64 KiB of dynamic LDS once per kernel instantiation
-        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<128>());
-        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<64>());
-        attr_done = true;
-    }
     a.gx = (int)icl_ceil_div(a.M, CV_BM);
-    icl_prof_scope ps(ctx, a.Cout % 128 == 0 ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
-    const int nst = a.K / T::BK > 1 ? 2 : 1; // single-k-step layers need one stage only -> more workgroups per CU
+    const int nk = a.K / T::BK;
+    const int mode = conv_mode_env();
+    // deep = 128x64 tile, 3 stages.  Default: layers with 2..8 k-steps whose grid still fills the chip with 64-wide tiles
+    bool deep = false;
+    if (mode == 1) deep = nk >= 2;
+    icl_prof_scope ps(ctx, (a.Cout % 128 == 0 && !deep) ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    const bool sel = nk >= 2 && nk <= 8;
+    int early_max = 8; // EARLY (everything requested up front, refill after the MFMAs) for tiles of up to this many k-steps
+    if (mode >= 100) early_max = mode - 100;
+    const bool early = nk <= early_max;
     if (a.X2) {
-        static bool dual_attr = false;
-        if (!dual_attr) {
-            (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<128>());
-            dual_attr = true;
-        }
-        a.gy = a.Cout / 128;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128, true>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(2), ctx->stream, a);
-    } else if (a.Cout % 128 == 0) {
-        a.gy = a.Cout / 128;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<128>(nst), ctx->stream, a);
+        if (deep) launch_conv_variant<T, 64, true, 3>(ctx, a, 3);
+        else if (mode == 2 && sel) launch_conv_variant<T, 128, true, 3>(ctx, a, 3);
+        else if (mode == 3 && sel) launch_conv_variant<T, 64, true, 2>(ctx, a, 2);
+        else if (early) launch_conv_variant<T, 128, true, 2, true>(ctx, a, 2);
+        else launch_conv_variant<T, 128, true, 2>(ctx, a, 2);
+    } else if (a.Cout % 128 == 0 && !deep) {
+        if (mode == 2 && sel) launch_conv_variant<T, 128, false, 3>(ctx, a, 3);
+        else if (mode == 3 && sel) launch_conv_variant<T, 64, false, 2>(ctx, a, 2);
+        else if (early) launch_conv_variant<T, 128, false, 2, true>(ctx, a, nk > 1 ? 2 : 1);
+        else launch_conv_variant<T, 128, false, 2>(ctx, a, nk > 1 ? 2 : 1); // single-k-step layers need one stage only -> more workgroups per CU
+    } else if (deep) {
+        launch_conv_variant<T, 64, false, 3>(ctx, a, 3);
     } else {
-        a.gy = a.Cout / 64;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<64>(nst), ctx->stream, a);
+        if (early) launch_conv_variant<T, 64, false, 2, true>(ctx, a, nk > 1 ? 2 : 1);
+        else launch_conv_variant<T, 64, false, 2>(ctx, a, nk > 1 ? 2 : 1);
     }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
@@ -788,6 +879,7 @@ static int launch_conv(icl_ctx *ctx, int prec, const conv_layer &L, const void *
     a.M = (int64_t)B * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Cin;
     const int bk = prec == ICL_PREC_BF16 ? BF16::BK : F32::BK;
+    if (a.M >= (1LL << 31)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "conv: %lld output pixels exceed the kernel's 32-bit pixel index", (long long)a.M);
     if (a.Cin % bk || a.Cout % 64 || a.K != L.K)
         return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "conv shape cin=%d cout=%d k=%d not supported by the implicit-GEMM kernel", a.Cin, a.Cout, a.KH);
     return prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
