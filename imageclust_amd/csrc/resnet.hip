@@ -50,25 +50,34 @@ struct conv_resid {
     static constexpr int NPASS = 64 / (256 / (BN / T::KE));
     uint4 v[2][NPASS];
 };
-template <typename T, int BN>
+template <typename T, int BN, bool FULL>
 __device__ __forceinline__ void conv_resid_load(const conv_args &p, conv_resid<T, BN> &r, int64_t m0, int n0, int tid)
 {
     typedef typename T::elem elem;
     constexpr int CPR = BN / T::KE, RPP = 256 / CPR, NPASS = 64 / RPP;
     const elem *Rg = (const elem *)p.R;
     const int nl = (tid % CPR) * T::KE;
+    if (!Rg) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) r.v[half][i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const elem *r0 = Rg + (m0 + tid / CPR) * p.Cout + n0 + nl; // one 64-bit row address, then uniform strides
+    const int64_t pstride = (int64_t)RPP * p.Cout;
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int64_t m = m0 + half * 64 + tid / CPR + i * RPP;
-            r.v[half][i] = (Rg && m < p.M) ? *reinterpret_cast<const uint4 *>(Rg + m * p.Cout + n0 + nl) : make_uint4(0, 0, 0, 0);
+            r.v[half][i] = (FULL || m < p.M) ? *reinterpret_cast<const uint4 *>(r0 + (half * NPASS + i) * pstride) : make_uint4(0, 0, 0, 0);
         }
 }
 
-template <typename T, int BN, bool TILE2D = false>
+template <typename T, int BN, bool TILE2D = false, bool FULL = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char *smem, f32x16 (&acc)[BN / 64][2], int64_t m0, int n0,
-                                              int tid, int wm, int wn, int fr, int fh, const conv_resid<T, BN> *pre = nullptr)
+                                              int tid, int wm, int wn, int fr, int fh, const conv_resid<T, BN> &pre)
 {
     // TILE2D (stem): tile row r is pixel (r/16, r%16) of an 8x16 patch whose top-left output pixel is m0
     auto row_m = [&](int ml) -> int64_t { return TILE2D ? m0 + (int64_t)(ml >> 4) * p.Wo + (ml & 15) : m0 + ml; };
@@ -82,6 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     constexpr int RPP = 256 / CPR;    // tile rows covered per pass
     constexpr int NPASS = 64 / RPP;   // passes per 64-row half tile
     const int nl = (tid % CPR) * T::KE;
+    elem *Yfull = Yg + (m0 + tid / CPR) * p.Cout + n0 + nl;
     float sc[T::KE], sh[T::KE];
 #pragma unroll
     for (int q = 0; q < T::KE; q += 4) {
@@ -96,9 +106,9 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
     for (int half = 0; half < 2; ++half) {
         // all residual loads of the lane for this half are issued before any arithmetic
         uint4 rv[NPASS];
-        if (pre) {
+        if (PRE) {
 #pragma unroll
-            for (int i = 0; i < NPASS; ++i) rv[i] = pre->v[half][i];
+            for (int i = 0; i < NPASS; ++i) rv[i] = pre.v[half][i];
         } else if (Rg) {
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
@@ -126,7 +136,7 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
         for (int i = 0; i < NPASS; ++i) {
             const int ml = tid / CPR + i * RPP;
             const int64_t m = row_m(half * 64 + ml);
-            if (m >= p.M) break;
+            if (!FULL && m >= p.M) break;
             float v[T::KE];
 #pragma unroll
             for (int q = 0; q < T::KE; q += 4) {
@@ -143,13 +153,16 @@ __device__ __forceinline__ void conv_epilogue(const conv_args &p, unsigned char 
             }
             if (p.relu) {
 #pragma unroll
-                for (int q = 0; q < T::KE; ++q) v[q] = v[q] > 0.0f ? v[q] : 0.0f;
+                for (int q = 0; q < T::KE; ++q) v[q] = fmaxf(v[q], 0.0f);
             }
             uint4 ov;
             elem *oe = reinterpret_cast<elem *>(&ov);
 #pragma unroll
             for (int q = 0; q < T::KE; ++q) oe[q] = T::from_f(v[q]);
-            *reinterpret_cast<uint4 *>(Yg + m * p.Cout + n0 + nl) = ov;
+            if (FULL && !TILE2D) // whole tile inside M: one 64-bit row address, then uniform strides
+                *reinterpret_cast<uint4 *>(Yfull + (int64_t)(half * NPASS + i) * ((int64_t)RPP * p.Cout)) = ov;
+            else
+                *reinterpret_cast<uint4 *>(Yg + m * p.Cout + n0 + nl) = ov;
         }
     }
 }
@@ -261,8 +274,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         // load round trips on its critical path.  Everything that can be requested at once is: the residual chunks of
         // the epilogue first, then BOTH stages; a stage buffer is refilled as soon as its step's MFMAs are done
         // (a second barrier per k-step), so two k-steps stay in flight.
+        const bool full = m0 + CV_BM <= p.M; // every tile but the last along M
         conv_resid<T, BN> res;
-        conv_resid_load<T, BN>(p, res, m0, n0, tid);
+        if (full) conv_resid_load<T, BN, true>(p, res, m0, n0, tid);
+        else conv_resid_load<T, BN, false>(p, res, m0, n0, tid);
         stage(0);
         if (nk > 1) stage(1);
         for (int ks = 0; ks < nk; ++ks) {
@@ -277,7 +292,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
             }
         }
         __syncthreads(); // the epilogue reuses the staging buffers
-        conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, &res);
+        if (full) conv_epilogue<T, BN, false, true, true>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, res);
+        else conv_epilogue<T, BN, false, false, true>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, res);
         return;
     }
     // NST-stage ring, NST-1 k-steps of LDS-DMA in flight
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
         conv_mma_kstep<T, BN>(wsm, wsm + BN * CV_ROWB, wm, wn, fr, fh, acc);
     }
     __syncthreads(); // the epilogue reuses the staging buffers
-    conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh);
+    conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
 }
 
 template <int BN>
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
         conv_mma_kstep<T, BN>(smem + j * WST, smem + NKS * WST + (j & 1) * XST, wm, wn, fr, fh, acc);
         __syncthreads();
     }
-    conv_epilogue<T, BN, true>(p, smem, acc, m0, 0, tid, wm, wn, fr, fh);
+    conv_epilogue<T, BN, true>(p, smem, acc, m0, 0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
 }
 
 template <typename T>
@@ -831,7 +847,7 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     if (mode == 1) deep = nk >= 2;
     icl_prof_scope ps(ctx, (a.Cout % 128 == 0 && !deep) ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
     const bool sel = nk >= 2 && nk <= 8;
-    int early_max = 8; // EARLY (everything requested up front, refill after the MFMAs) for tiles of up to this many k-steps
+    int early_max = 1 << 30; // EARLY (everything requested up front, refill after the MFMAs) for tiles of up to this many k-steps
     if (mode >= 100) early_max = mode - 100;
     const bool early = nk <= early_max;
     if (a.X2) {
