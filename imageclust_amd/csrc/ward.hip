@@ -924,7 +924,14 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
 // excluded, c_0..c_{j-1} are included (as "virtual slots" whose columns are the new centroids).
 // ============================================================================================================
 #define WB_P 6
+#ifndef WB_PRING
+#define WB_PRING 0                    /* 1: producers square the differences (ring of p per chain): measured SLOWER (update 50 us vs 37 us per launch, the ds_write_b128 path saturates); 0: chain waves do (ring of x) */
+#endif
+#if WB_PRING
+#define WB_GP 2
+#else
 #define WB_GP 4
+#endif
 #define WB_SG (WB_P * WB_GP)          /* k-groups per stage */
 #define WB_KC 4                        /* chain waves per workgroup: one per SIMD */
 #define WB_NH (WB_K / WB_KC)            /* workgroups sharing a 64-slot block, each with WB_KC of the batch's chains */
@@ -1348,8 +1355,14 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
                                                                       float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // [2][WB_SG][64] x ring, then [WB_K][dqp+pad] centroids
+    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring (x: [2][WB_SG][64], p: [2][WB_KC][WB_SG][64]), then [WB_KC][dqp+pad] centroids
+#if WB_PRING
+    float4 (*ring)[WB_KC][WB_SG][64] = reinterpret_cast<float4 (*)[WB_KC][WB_SG][64]>(wb_lds);
+    constexpr int RING_F4 = 2 * WB_KC * WB_SG * 64;
+#else
     float4 (*ring)[WB_SG][64] = reinterpret_cast<float4 (*)[WB_SG][64]>(wb_lds);
+    constexpr int RING_F4 = 2 * WB_SG * 64;
+#endif
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
@@ -1391,8 +1404,8 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     const int64_t row_bytes = virt ? 16 : S * 16;
     const int pj = wave - WB_KC; // producer index (waves WB_KC..), chain index = half*WB_KC + wave (waves 0..WB_KC-1)
     const bool producer = wave >= WB_KC;
-    struct xq { float4 g0, g1, g2, g3; }; // WB_GP == 4 k-groups of one slot, kept in named registers
-    static_assert(WB_GP == 4, "xq holds four groups");
+    struct xq { float4 g0, g1, g2, g3; }; // WB_GP (2 or 4) k-groups of one slot, kept in named registers
+    static_assert(WB_GP == 4 || WB_GP == 2, "xq holds two or four groups");
     // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
     // streams its centroid from the row-major copy instead and re-makes the column on the way
     bool dirty_lane = false;
@@ -1405,14 +1418,18 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             const char *cr = reinterpret_cast<const char *>(Crow) + ((int64_t)slot * d + (int64_t)g0 * 4) * 4;
             if (g0 + 0 < dq_real) r0 = cr;
             if (g0 + 1 < dq_real) r1 = cr + 16;
-            if (g0 + 2 < dq_real) r2 = cr + 32;
-            if (g0 + 3 < dq_real) r3 = cr + 48;
+            if (WB_GP == 4 && g0 + 2 < dq_real) r2 = cr + 32;
+            if (WB_GP == 4 && g0 + 3 < dq_real) r3 = cr + 48;
         }
         xq v;
         v.g0 = *reinterpret_cast<const float4 *>(r0);
         v.g1 = *reinterpret_cast<const float4 *>(r1);
-        v.g2 = *reinterpret_cast<const float4 *>(r2);
-        v.g3 = *reinterpret_cast<const float4 *>(r3);
+        if (WB_GP == 4) {
+            v.g2 = *reinterpret_cast<const float4 *>(r2);
+            v.g3 = *reinterpret_cast<const float4 *>(r3);
+        } else {
+            v.g2 = v.g3 = make_float4(0, 0, 0, 0);
+        }
         return v;
     };
     xq va = {}, vb = {}, vc = {};
@@ -1466,7 +1483,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         }
         return;
     }
-    float4 *cn4 = wb_lds + 2 * WB_SG * 64;
+    float4 *cn4 = wb_lds + RING_F4;
     const int cnl = dqp + WB_PAD_G; // float4s per centroid image in LDS
     const int nch = nb - half * WB_KC < WB_KC ? nb - half * WB_KC : WB_KC; // chains run here
     for (int j = 0; j < nch; ++j)
@@ -1474,23 +1491,60 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             cn4[j * cnl + g] = reinterpret_cast<const float4 *>(cnewK + (half * WB_KC + j) * cn_stride)[g];
     __syncthreads();
     float s = 0.0f;
-    // producers only move x (global -> LDS); every chain wave squares its own differences: the 8 VALU instructions per
-    // 4 k (2 pk_sub, 2 pk_mul, 4 dependent adds) issue in about the time the 4 dependent adds take anyway, and the ring
-    // is written once per column instead of once per (column, chain) -- ds_write_b128 is the expensive LDS operation
+    auto patch_ct = [&](const xq &v, int stage) { // re-make a dirty column (both workgroups of a slot block write the same values)
+        if (dirty_lane && stage >= 2) {
+            const int g0 = stage * WB_SG + pj * WB_GP;
+            if (g0 + 0 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 0, S, slot)) = v.g0;
+            if (g0 + 1 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 1, S, slot)) = v.g1;
+            if (WB_GP == 4 && g0 + 2 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 2, S, slot)) = v.g2;
+            if (WB_GP == 4 && g0 + 3 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 3, S, slot)) = v.g3;
+        }
+    };
+    const bool chain = wave < nch;
+#if WB_PRING
+    // producers stream x once and square its differences to this workgroup's WB_KC new centroids: a chain wave then
+    // only reads p and adds (5 instructions per 4 k instead of 10 -- the chain wave's instruction stream is the
+    // critical path); the price is WB_KC ds_write_b128 per column group, the expensive LDS operation
+    auto sq = [&](const float4 &xv, const float4 &cv) {
+        const f2 xa = {xv.x, xv.y}, xb = {xv.z, xv.w};
+        const f2 ca = {cv.x, cv.y}, cb = {cv.z, cv.w};
+        const f2 da = xa - ca, db = xb - cb; // clustering.go:139 via :84
+        const f2 qa = da * da, qb = db * db; // :154 products, each rounded
+        return make_float4(qa.x, qa.y, qb.x, qb.y);
+    };
+    auto produce = [&](const xq &v, int buf, int stage) {
+        const int g0 = stage * WB_SG + pj * WB_GP;
+#pragma unroll
+        for (int j = 0; j < WB_KC; ++j) {
+            if (j < nch) {
+                ring[buf][j][pj * WB_GP + 0][lane] = sq(v.g0, cn4[j * cnl + g0 + 0]);
+                ring[buf][j][pj * WB_GP + 1][lane] = sq(v.g1, cn4[j * cnl + g0 + 1]);
+            }
+        }
+        patch_ct(v, stage);
+    };
+    auto consume = [&](int buf, int stage) {
+        (void)stage;
+        float4 pv[WB_SG];
+#pragma unroll
+        for (int g = 0; g < WB_SG; ++g) pv[g] = ring[buf][wave][g][lane];
+#pragma unroll
+        for (int g = 0; g < WB_SG; ++g) {
+            s = s + pv[g].x; // :154 the running sum, strictly in k order
+            s = s + pv[g].y;
+            s = s + pv[g].z;
+            s = s + pv[g].w;
+        }
+    };
+#else
+    // producers only move x (global -> LDS); every chain wave squares its own differences
     auto produce = [&](const xq &v, int buf, int stage) {
         ring[buf][pj * WB_GP + 0][lane] = v.g0;
         ring[buf][pj * WB_GP + 1][lane] = v.g1;
         ring[buf][pj * WB_GP + 2][lane] = v.g2;
         ring[buf][pj * WB_GP + 3][lane] = v.g3;
-        if (dirty_lane && stage >= 2) { // re-make the column (both workgroups of a slot block write the same values)
-            const int g0 = stage * WB_SG + pj * WB_GP;
-            if (g0 + 0 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 0, S, slot)) = v.g0;
-            if (g0 + 1 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 1, S, slot)) = v.g1;
-            if (g0 + 2 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 2, S, slot)) = v.g2;
-            if (g0 + 3 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 3, S, slot)) = v.g3;
-        }
+        patch_ct(v, stage);
     };
-    const bool chain = wave < nch;
     const float4 *cnj = cn4 + (chain ? wave : 0) * cnl;
     auto consume = [&](int buf, int stage) {
         const float4 *cs = cnj + stage * WB_SG;
@@ -1515,6 +1569,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             }
         }
     };
+#endif
     const int nstage = dqp / WB_SG;
     for (int i = 0; i < nstage; i += 3) {
         if (producer) {
@@ -2597,7 +2652,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // dependent (between T/WB_K and T).  Steps are enqueued in chunks of GRAPH_STEPS; the state is read back after
         // each chunk, one chunk behind the launches so the queue never drains.
         const int dqb = (int)wb_groups(d);
-        const size_t wb_lds_bytes = (size_t)2 * WB_SG * 64 * 16 + (size_t)WB_KC * (dqb + WB_PAD_G) * 16;
+        const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * (dqb + WB_PAD_G) * 16;
         if (wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
         static bool wb_attr = false;
         if (!wb_attr) {
