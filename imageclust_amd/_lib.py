@@ -59,6 +59,7 @@ SYMBOLS = [
     ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_cluster_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_last_merges", _i64, [_vp, _vp, _i64]),
+    ("icl_last_merge_values", _i64, [_vp, _vp, _i64]),
     ("icl_distance_mfma_dev", _int, [_vp, _vp, _i64, _i32, _vp, _i64]),
     ("icl_synth_images", _int, [C.c_uint64, _i64, _i64, _int, _vp]),
     ("icl_synth_images_dev", _int, [_vp, C.c_uint64, _i64, _i64, _int, _vp]),
@@ -305,6 +306,13 @@ class Context:
         n = self.L.icl_last_merges(self.h, None, 0)
         out = np.zeros((max(n, 1), 2), np.int32)
         self.L.icl_last_merges(self.h, out.ctypes.data, n)
+        return out[:n]
+
+    def last_merge_values(self):
+        """Ward distance of the pair joined by each merge of last_merges() (the dendrogram heights)."""
+        n = self.L.icl_last_merge_values(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.float32)
+        self.L.icl_last_merge_values(self.h, out.ctypes.data, n)
         return out[:n]
 
 

@@ -138,3 +138,32 @@ def clusters_as_map(cluster_id, member_rank, ids) -> Dict[int, List[str]]:
         if c >= 0:
             out.setdefault(c, []).append(ids[i])
     return out
+
+
+
+# ---- dendrogram export -----------------------------------------------------------------------
+def LastDendrogram(n: int, ctx: Optional[_lib.Context] = None) -> np.ndarray:
+    """The merge tree of the last PerformClusteringWithConstraints / cluster call as a scipy-style linkage matrix
+    Z[t] = [id_a, id_b, ward_distance, size]: singleton i has id i, the cluster created by merge t has id n+t (the
+    engine's creation ids are exactly that convention).  The reference stops at k clusters (clustering.go:220), so Z has
+    n-k rows: a forest cut at the size constraints, not a full tree.  Heights are the values FindClosestClusters
+    returned (clustering.go:123-131), i.e. WardDistance of the merged pair (:84) -- not scipy's sqrt(2*d) scale."""
+    ctx = ctx or default_context()
+    m = ctx.last_merges().astype(np.int64)
+    v = ctx.last_merge_values().astype(np.float64)
+    size = np.ones(n + len(m), np.int64)
+    Z = np.zeros((len(m), 4), np.float64)
+    for t, (a, b) in enumerate(m):
+        size[n + t] = size[a] + size[b]
+        Z[t] = (a, b, v[t], size[n + t])
+    return Z
+
+
+def ExportDendrogram(path: str, Z: np.ndarray, ids: Optional[List[str]] = None):
+    """Writes the linkage matrix (and the item ids) as JSON: {"n", "ids", "merges": [[a, b, height, size], ...]}."""
+    import json
+
+    n = int(len(ids)) if ids is not None else int(Z[:, :2].max() + 2 - len(Z)) if len(Z) else 0
+    with open(path, "w") as f:
+        json.dump({"n": n, "ids": list(ids) if ids is not None else None,
+                   "merges": [[int(r[0]), int(r[1]), float(r[2]), int(r[3])] for r in Z]}, f)

@@ -47,6 +47,7 @@ struct icl_ctx {
     icl_model *model = nullptr;
     icl_ward_ws *ward = nullptr;
     std::vector<int32_t> last_merges; // pairs
+    std::vector<float> last_merge_vals; // Ward distance of each merged pair
 };
 
 int icl_fail(icl_ctx *ctx, int code, const char *fmt, ...);

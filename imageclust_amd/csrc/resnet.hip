@@ -859,6 +859,8 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     } else if (a.Cout % 128 == 0 && !deep) {
         if (mode == 2 && sel) launch_conv_variant<T, 128, false, 3>(ctx, a, 3);
         else if (mode == 3 && sel) launch_conv_variant<T, 64, false, 2>(ctx, a, 2);
+        else if (mode == 4 && nk >= 16) launch_conv_variant<T, 128, false, 4>(ctx, a, 4);
+        else if (mode == 5 && nk >= 16) launch_conv_variant<T, 128, false, 3>(ctx, a, 3);
         else if (early) launch_conv_variant<T, 128, false, 2, true>(ctx, a, nk > 1 ? 2 : 1);
         else launch_conv_variant<T, 128, false, 2>(ctx, a, nk > 1 ? 2 : 1); // single-k-step layers need one stage only -> more workgroups per CU
     } else if (deep) {

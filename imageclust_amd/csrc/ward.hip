@@ -589,7 +589,7 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
                                                           int32_t *__restrict__ rownn, int32_t *__restrict__ merges,
                                                           ward_state *__restrict__ st)
 {
-    __shared__ int sh[6];
+    __shared__ int sh[7];
     if (st->done) return;
     const int t = st->t;
     if (threadIdx.x == 0) {
@@ -619,9 +619,11 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
             if (cx >= 0 && (pr < 0 || cv < pv)) { // strict '<': on equal values the lower row index (pr < c) wins
                 a = c;
                 b = cx;
+                sh[6] = (int)__float_as_uint(cv);
             } else if (pr >= 0) {
                 a = pr;
                 b = st->pre_nn;
+                sh[6] = (int)__float_as_uint(pv);
             }
             if (a < 0) {
                 st->done = 1; // clustering.go:222-225 "No more clusters to merge."
@@ -658,8 +660,9 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
         CT[ct4_off(k >> 2, S, slot_a) + (k & 3)] = cv;
     }
     if (threadIdx.x == 0) {
-        merges[2 * t] = a;
-        merges[2 * t + 1] = b;
+        merges[3 * t] = a;
+        merges[3 * t + 1] = b;
+        merges[3 * t + 2] = sh[6]; // the pair's Ward distance (float bits): the dendrogram height
         asz[a] = 0;
         asz[b] = 0;
         asz[c] = sa + sb;
@@ -1767,8 +1770,9 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             const int j = lane;
             const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
             const unsigned long long key = ls.B.ckey[j];
-            merges[2 * (t0 + j)] = a;
-            merges[2 * (t0 + j) + 1] = b;
+            merges[3 * (t0 + j)] = a;
+            merges[3 * (t0 + j) + 1] = b;
+            merges[3 * (t0 + j) + 2] = (int)__float_as_uint(ls.B.val[j]); // the pair's Ward distance: the dendrogram height
             asz[a] = 0;
             asz[b] = 0;
             asz[c] = ls.B.sa[j] + ls.B.sb[j];
@@ -2357,7 +2361,7 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rownn, int32_t, w->M);
         WS_ALLOC(rowoff, int64_t, w->M + 1);
         WS_ALLOC(Dtri, float, w->dtri_floats);
-        WS_ALLOC(merges, int32_t, 2 * n + 2);
+        WS_ALLOC(merges, int32_t, 3 * n + 3);
         WS_ALLOC(st, ward_state, 1);
         ICL_HIP(ctx, hipMemcpyAsync(w->rowoff, w->h_rowoff.data(), (size_t)(w->M + 1) * sizeof(int64_t),
                                     hipMemcpyHostToDevice, ctx->stream));
@@ -2775,10 +2779,16 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ctx->ward_stats[2] = nmerge;
         ctx->ward_stats[3] = (int64_t)nmerge * n - (int64_t)nmerge * (nmerge + 1) / 2;
     }
-    std::vector<int32_t> pairs((size_t)(2 * nmerge));
+    std::vector<int32_t> pairs((size_t)(2 * nmerge)), trip((size_t)(3 * nmerge));
+    ctx->last_merge_vals.assign((size_t)nmerge, 0.0f);
     if (nmerge) {
-        ICL_HIP(ctx, hipMemcpyAsync(pairs.data(), w->merges, (size_t)(2 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ICL_HIP(ctx, hipMemcpyAsync(trip.data(), w->merges, (size_t)(3 * nmerge) * 4, hipMemcpyDeviceToHost, ctx->stream));
         ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t q = 0; q < nmerge; ++q) {
+            pairs[(size_t)(2 * q)] = trip[(size_t)(3 * q)];
+            pairs[(size_t)(2 * q + 1)] = trip[(size_t)(3 * q + 1)];
+            memcpy(&ctx->last_merge_vals[(size_t)q], &trip[(size_t)(3 * q + 2)], 4);
+        }
     }
     float ms01 = 0, ms12 = 0;
     (void)hipEventElapsedTime(&ms01, e0, e1);
@@ -2857,6 +2867,16 @@ extern "C" int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, con
     (void)hipFree(buf);
     if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "icl_merge_centroid: %s", hipGetErrorString(e));
     return ICL_OK;
+}
+
+extern "C" int64_t icl_last_merge_values(icl_ctx *ctx, float *vals, int64_t cap)
+{
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int64_t nm = (int64_t)ctx->last_merge_vals.size();
+    if (vals)
+        for (int64_t t = 0; t < nm && t < cap; ++t) vals[t] = ctx->last_merge_vals[(size_t)t];
+    return nm;
 }
 
 extern "C" int icl_last_ward_stats(icl_ctx *ctx, int64_t *merges, int64_t *steps, int64_t *single_pick_steps, int64_t *sum_live)

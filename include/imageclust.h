@@ -120,6 +120,9 @@ int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
  * cluster, creation id of the lower-position one); returns the number of merges performed. */
 int64_t icl_last_merges(icl_ctx *ctx, int32_t *pairs, int64_t cap_pairs);
+/* Ward distance (clustering.go:84) of the pair joined by each merge of that log, i.e. the dendrogram heights: the
+ * value FindClosestClusters found (:123-131).  Returns the number of merges; fills min(cap, merges) values. */
+int64_t icl_last_merge_values(icl_ctx *ctx, float *vals, int64_t cap);
 /* MFMA distance tile alone (north_star K6): D~[i][j] = 0.5*(|e_i|^2+|e_j|^2-2 e_i.e_j), bf16x3 split operands,
  * fp32 accumulate; lower triangle incl. diagonal written, packed row-major with leading dimension ld. */
 int icl_distance_mfma_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, float *d_D, int64_t ld);

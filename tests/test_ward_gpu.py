@@ -252,6 +252,33 @@ def test_cluster_property_sizes_at_scale(ctx):
     assert np.array_equal(cid, cid2) and np.array_equal(rank, rank2)
 
 
+def test_merge_values_and_dendrogram(ctx, CL, tmp_path):
+    """icl_last_merge_values = WardDistance (clustering.go:84) of every merged pair, bit for bit: replay the merge log
+    with the oracle's centroid / distance helpers."""
+    import json
+
+    n, d = 180, 24
+    E = mog(n, d, 77, k=12)
+    cid, rank, nc = ctx.cluster(E, 2, 9)
+    m = ctx.last_merges()
+    v = ctx.last_merge_values()
+    assert len(v) == len(m) > 0
+    cen = {i: E[i].copy() for i in range(n)}
+    size = {i: 1 for i in range(n)}
+    for t, (a, b) in enumerate(m.tolist()):
+        want = O.ward_distance(cen[a], size[a], cen[b], size[b])
+        assert np.float32(v[t]).view(np.uint32) == np.float32(want).view(np.uint32), "merge %d" % t
+        cen[n + t] = O.merge_centroid(cen[a], size[a], cen[b], size[b])
+        size[n + t] = size[a] + size[b]
+    Z = CL.LastDendrogram(n, ctx)
+    assert Z.shape == (len(m), 4) and np.array_equal(Z[:, :2].astype(np.int32), m)
+    assert np.array_equal(Z[:, 2].astype(np.float32), v) and Z[-1, 3] == size[n + len(m) - 1]
+    p = str(tmp_path / "dendro.json")
+    CL.ExportDendrogram(p, Z, ids(n))
+    J = json.load(open(p))
+    assert J["n"] == n and len(J["merges"]) == len(m) and J["merges"][0][:2] == m[0].tolist()
+
+
 def test_golden_fixtures(ctx):
     import os
 
