@@ -5,9 +5,11 @@
 // settings: integer "islow" IDCT, "fancy" (triangle) chroma upsampling and the fixed-point YCbCr->RGB tables.  Those
 // three algorithms are public (IJG libjpeg: jidctint.c, jdsample.c, jdcolor.c) and are restated here so that decoded
 // pixels are bit-identical to libjpeg-turbo's (checked against Pillow's bundled libjpeg-turbo in
-// tests/test_jpeg_decode.py).  Supported: 8-bit baseline / extended sequential Huffman (SOF0, SOF1), 1 or 3
-// components, 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals, JFIF / Adobe-transform markers.
-// Progressive (SOF2), arithmetic coding, 12-bit and CMYK return ICL_ERR_UNSUPPORTED.
+// tests/test_jpeg_decode.py).  Supported: 8-bit baseline / extended sequential (SOF0, SOF1) and PROGRESSIVE (SOF2:
+// spectral selection + successive approximation, ITU T.81 annex G) Huffman streams, interleaved or one scan per
+// component, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals, JFIF / Adobe-transform markers.
+// Every scan decodes into per-component coefficient arrays; dequantisation + IDCT run once after the last scan.
+// Arithmetic coding, lossless, 12-bit and CMYK return ICL_ERR_UNSUPPORTED.
 #include "icl_common.h"
 
 #include <cstring>
@@ -52,6 +54,7 @@ struct component {
     int dw = 0, dh = 0;           // downsampled_width / _height (real samples)
     int pred = 0;
     std::vector<uint8_t> plane;   // wblocks*8 x hblocks*8
+    std::vector<int16_t> coefs;   // wblocks*hblocks blocks of 64, natural order, NOT dequantised
 };
 
 struct bit_reader {
@@ -222,12 +225,12 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
     bool qt_ok[4] = {false, false, false, false};
     huff_table dc[4], ac[4];
     component comp[3];
-    int ncomp = 0, restart = 0, hmax = 1, vmax = 1;
-    bool have_sof = false, adobe = false, decoded = false;
+    int ncomp = 0, restart = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, nscans = 0;
+    bool have_sof = false, adobe = false, progressive = false;
     int adobe_transform = -1;
     size_t pos = 2;
     W = H = 0;
-    while (pos + 4 <= len && !decoded) {
+    while (pos + 4 <= len) {
         if (data[pos] != 0xFF) { ++pos; continue; }
         const int m = data[pos + 1];
         if (m == 0xFF) { ++pos; continue; }
@@ -267,8 +270,10 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
                 t.present = true;
                 t.build();
             }
-        } else if (m == 0xC0 || m == 0xC1) { // SOF0 / SOF1
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) { // SOF0 / SOF1 / SOF2
+            if (have_sof) return fail(ICL_ERR_IO, "Second frame header");
             if (sl < 6 || s[0] != 8) return fail(ICL_ERR_UNSUPPORTED, "Only 8-bit JPEG is decoded");
+            progressive = m == 0xC2;
             H = (s[1] << 8) | s[2];
             W = (s[3] << 8) | s[4];
             ncomp = s[5];
@@ -279,20 +284,39 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
                 comp[c].h = s[7 + 3 * c] >> 4;
                 comp[c].v = s[7 + 3 * c] & 15;
                 comp[c].tq = s[8 + 3 * c];
+            }
+            if (ncomp == 1) comp[0].h = comp[0].v = 1;
+            if (ncomp == 3) {
+                const bool ok = comp[1].h == 1 && comp[1].v == 1 && comp[2].h == 1 && comp[2].v == 1 && (comp[0].h == 1 || comp[0].h == 2) &&
+                                (comp[0].v == 1 || comp[0].v == 2) && !(comp[0].h == 1 && comp[0].v == 2);
+                if (!ok) return fail(ICL_ERR_UNSUPPORTED, "Only 4:4:4, 4:2:2 and 4:2:0 chroma sampling is decoded");
+            }
+            for (int c = 0; c < ncomp; ++c) {
                 hmax = std::max(hmax, comp[c].h);
                 vmax = std::max(vmax, comp[c].v);
             }
+            mcux = (W + 8 * hmax - 1) / (8 * hmax);
+            mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            for (int c = 0; c < ncomp; ++c) {
+                component &k = comp[c];
+                k.wblocks = mcux * k.h;
+                k.hblocks = mcuy * k.v;
+                k.dw = (W * k.h + hmax - 1) / hmax;
+                k.dh = (H * k.v + vmax - 1) / vmax;
+                k.coefs.assign((size_t)k.wblocks * k.hblocks * 64, 0);
+            }
             have_sof = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            return fail(ICL_ERR_UNSUPPORTED, "Progressive / lossless / arithmetic JPEG is not decoded by this build (baseline only)");
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return fail(ICL_ERR_UNSUPPORTED, "Lossless / hierarchical / arithmetic-coded JPEG is not decoded by this build");
         } else if (m == 0xDD) {
             if (sl >= 2) restart = (s[0] << 8) | s[1];
         } else if (m == 0xEE) {
             if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
-        } else if (m == 0xDA) { // SOS: the whole (single) scan of a baseline file
+        } else if (m == 0xDA) { // SOS: one scan (a baseline file has one or ncomp of them, a progressive file many)
             if (!have_sof) return fail(ICL_ERR_IO, "Scan before frame header");
             const int ns = s[0];
-            if (ns != ncomp || sl < (size_t)(1 + 2 * ns + 3)) return fail(ICL_ERR_UNSUPPORTED, "Non-interleaved multi-scan JPEG is not decoded");
+            if (ns < 1 || ns > ncomp || sl < (size_t)(1 + 2 * ns + 3)) return fail(ICL_ERR_IO, "Bad scan header");
+            int sc[3];
             for (int i = 0; i < ns; ++i) {
                 int ci = -1;
                 for (int c = 0; c < ncomp; ++c)
@@ -300,73 +324,180 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
                 if (ci < 0) return fail(ICL_ERR_IO, "Bad scan component");
                 comp[ci].td = s[2 + 2 * i] >> 4;
                 comp[ci].ta = s[2 + 2 * i] & 15;
+                sc[i] = ci;
             }
-            if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }
-            if (ncomp == 3) {
-                const bool ok = comp[1].h == 1 && comp[1].v == 1 && comp[2].h == 1 && comp[2].v == 1 && (comp[0].h == 1 || comp[0].h == 2) &&
-                                (comp[0].v == 1 || comp[0].v == 2) && !(comp[0].h == 1 && comp[0].v == 2);
-                if (!ok) return fail(ICL_ERR_UNSUPPORTED, "Only 4:4:4, 4:2:2 and 4:2:0 chroma sampling is decoded");
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (progressive) {
+                const bool ok = Ss <= Se && Se <= 63 && Al <= 13 && (Ss == 0 ? Se == 0 : ns == 1) && (Ah == 0 || Ah == Al + 1);
+                if (!ok) return fail(ICL_ERR_IO, "Bad progressive scan parameters");
+            } else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) {
+                return fail(ICL_ERR_IO, "Bad sequential scan parameters");
             }
-            const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-            for (int c = 0; c < ncomp; ++c) {
-                component &k = comp[c];
-                if (k.tq > 3 || !qt_ok[k.tq] || k.td > 3 || k.ta > 3 || !dc[k.td].present || !ac[k.ta].present) return fail(ICL_ERR_IO, "Missing table");
-                k.wblocks = mcux * k.h;
-                k.hblocks = mcuy * k.v;
-                k.dw = (W * k.h + hmax - 1) / hmax;
-                k.dh = (H * k.v + vmax - 1) / vmax;
-                k.plane.assign((size_t)k.wblocks * 8 * k.hblocks * 8, 0);
-                k.pred = 0;
+            for (int i = 0; i < ns; ++i) {
+                const component &k = comp[sc[i]];
+                const bool need_dc = Ss == 0 && Ah == 0, need_ac = Se > 0;
+                if (k.td > 3 || k.ta > 3 || (need_dc && !dc[k.td].present) || (need_ac && !ac[k.ta].present)) return fail(ICL_ERR_IO, "Missing table");
+                comp[sc[i]].pred = 0;
             }
             bit_reader br{data + pos + seglen, data + len};
-            int coef[64];
-            int rst_left = restart;
-            for (int my = 0; my < mcuy; ++my)
-                for (int mx = 0; mx < mcux; ++mx) {
-                    if (restart && rst_left == 0) {
-                        // byte-align, expect RSTn
-                        const uint8_t *q = br.p;
-                        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
-                        if (q + 1 >= br.end) return fail(ICL_ERR_IO, "Missing restart marker");
-                        br.p = q + 2;
-                        br.reset();
-                        for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
-                        rst_left = restart;
+            int eobrun = 0;
+            // one block of one scan into the coefficient array (T.81 F.2.2 sequential, G.1.2 progressive; the
+            // refinement pass follows the structure of IJG jdphuff.c decode_mcu_AC_refine)
+            auto decode_block = [&](component &k, int16_t *cf) -> bool {
+                if (!progressive) {
+                    const int t = huff_decode(br, dc[k.td]);
+                    if (t < 0 || t > 15) return false;
+                    k.pred += t ? extend(br.get(t), t) : 0;
+                    cf[0] = (int16_t)k.pred;
+                    for (int i = 1; i < 64;) {
+                        const int rs = huff_decode(br, ac[k.ta]);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) { i += 16; continue; }
+                            break;
+                        }
+                        i += r;
+                        if (i > 63) return false;
+                        cf[zigzag[i]] = (int16_t)extend(br.get(sz), sz);
+                        ++i;
                     }
-                    for (int c = 0; c < ncomp; ++c) {
-                        component &k = comp[c];
-                        for (int by = 0; by < k.v; ++by)
-                            for (int bx = 0; bx < k.h; ++bx) {
-                                memset(coef, 0, sizeof coef);
-                                int t = huff_decode(br, dc[k.td]);
-                                if (t < 0 || t > 15) return fail(ICL_ERR_IO, "Corrupt JPEG data");
-                                const int diff = t ? extend(br.get(t), t) : 0;
-                                k.pred += diff;
-                                coef[0] = k.pred * qt[k.tq][0];
-                                for (int i = 1; i < 64;) {
-                                    const int rs = huff_decode(br, ac[k.ta]);
-                                    if (rs < 0) return fail(ICL_ERR_IO, "Corrupt JPEG data");
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r == 15) { i += 16; continue; }
-                                        break;
-                                    }
-                                    i += r;
-                                    if (i > 63) return fail(ICL_ERR_IO, "Corrupt JPEG data");
-                                    coef[zigzag[i]] = extend(br.get(sz), sz) * qt[k.tq][zigzag[i]];
-                                    ++i;
-                                }
-                                const size_t stride = (size_t)k.wblocks * 8;
-                                idct_islow(coef, k.plane.data() + ((size_t)(my * k.v + by) * 8) * stride + (size_t)(mx * k.h + bx) * 8, (int)stride);
-                            }
-                    }
-                    if (restart) --rst_left;
+                    return true;
                 }
-            decoded = true;
+                if (Ss == 0) {
+                    if (Ah == 0) { // DC first
+                        const int t = huff_decode(br, dc[k.td]);
+                        if (t < 0 || t > 15) return false;
+                        k.pred += t ? extend(br.get(t), t) : 0;
+                        cf[0] = (int16_t)(k.pred * (1 << Al));
+                    } else if (br.get(1)) { // DC refinement: one more bit
+                        cf[0] = (int16_t)(cf[0] | (1 << Al));
+                    }
+                    return true;
+                }
+                if (Ah == 0) { // AC first
+                    if (eobrun > 0) { --eobrun; return true; }
+                    for (int i = Ss; i <= Se;) {
+                        const int rs = huff_decode(br, ac[k.ta]);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) { i += 16; continue; }
+                            eobrun = (1 << r) - 1;
+                            if (r) eobrun += br.get(r);
+                            break;
+                        }
+                        i += r;
+                        if (i > Se) return false;
+                        cf[zigzag[i]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+                        ++i;
+                    }
+                    return true;
+                }
+                // AC refinement
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                int i = Ss;
+                auto refine = [&](int16_t &c) {
+                    if (br.get(1) && (c & p1) == 0) c = (int16_t)(c + (c >= 0 ? p1 : m1));
+                };
+                if (eobrun == 0) {
+                    for (; i <= Se; ++i) {
+                        const int rs = huff_decode(br, ac[k.ta]);
+                        if (rs < 0) return false;
+                        int r = rs >> 4, sv = rs & 15;
+                        if (sv) {
+                            if (sv != 1) return false;
+                            sv = br.get(1) ? p1 : m1;
+                        } else if (r != 15) { // EOBr: the rest of this block (and eobrun-1 more) only gets correction bits
+                            eobrun = 1 << r;
+                            if (r) eobrun += br.get(r);
+                            break;
+                        }
+                        // skip r ZERO-history coefficients (ZRL: 16), refining the non-zero ones passed on the way
+                        for (; i <= Se; ++i) {
+                            int16_t &c = cf[zigzag[i]];
+                            if (c != 0) refine(c);
+                            else if (--r < 0) break;
+                        }
+                        if (sv) {
+                            if (i > Se) return false;
+                            cf[zigzag[i]] = (int16_t)sv;
+                        }
+                    }
+                }
+                if (eobrun > 0) {
+                    for (; i <= Se; ++i) {
+                        int16_t &c = cf[zigzag[i]];
+                        if (c != 0) refine(c);
+                    }
+                    --eobrun;
+                }
+                return true;
+            };
+            auto do_restart = [&]() -> bool {
+                const uint8_t *q = br.p; // byte-align, expect RSTn
+                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                if (q + 1 >= br.end) return false;
+                br.p = q + 2;
+                br.reset();
+                for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                eobrun = 0;
+                return true;
+            };
+            int rst_left = restart;
+            if (ns == 1) { // non-interleaved: the component's own block raster, one block per "MCU"
+                component &k = comp[sc[0]];
+                const int bw = (k.dw + 7) / 8, bh = (k.dh + 7) / 8;
+                for (int by = 0; by < bh; ++by)
+                    for (int bx = 0; bx < bw; ++bx) {
+                        if (restart && rst_left == 0) {
+                            if (!do_restart()) return fail(ICL_ERR_IO, "Missing restart marker");
+                            rst_left = restart;
+                        }
+                        if (!decode_block(k, k.coefs.data() + ((size_t)by * k.wblocks + bx) * 64)) return fail(ICL_ERR_IO, "Corrupt JPEG data");
+                        if (restart) --rst_left;
+                    }
+            } else {
+                for (int my = 0; my < mcuy; ++my)
+                    for (int mx = 0; mx < mcux; ++mx) {
+                        if (restart && rst_left == 0) {
+                            if (!do_restart()) return fail(ICL_ERR_IO, "Missing restart marker");
+                            rst_left = restart;
+                        }
+                        for (int i = 0; i < ns; ++i) {
+                            component &k = comp[sc[i]];
+                            for (int by = 0; by < k.v; ++by)
+                                for (int bx = 0; bx < k.h; ++bx)
+                                    if (!decode_block(k, k.coefs.data() + ((size_t)(my * k.v + by) * k.wblocks + (mx * k.h + bx)) * 64))
+                                        return fail(ICL_ERR_IO, "Corrupt JPEG data");
+                        }
+                        if (restart) --rst_left;
+                    }
+            }
+            ++nscans;
+            // continue at the marker that ended the entropy-coded segment
+            const uint8_t *q = br.p;
+            while (q + 1 < data + len && !(q[0] == 0xFF && q[1] != 0x00 && !(q[1] >= 0xD0 && q[1] <= 0xD7) && q[1] != 0xFF)) ++q;
+            pos = (size_t)(q - data);
+            continue;
         }
         pos += seglen;
     }
-    if (!decoded) return fail(ICL_ERR_IO, "The image file might be corrupt or unreadable");
+    if (!have_sof || nscans == 0) return fail(ICL_ERR_IO, "The image file might be corrupt or unreadable");
+    // dequantise + inverse DCT, once, after the last scan
+    for (int c = 0; c < ncomp; ++c) {
+        component &k = comp[c];
+        if (k.tq > 3 || !qt_ok[k.tq]) return fail(ICL_ERR_IO, "Missing table");
+        const size_t stride = (size_t)k.wblocks * 8;
+        k.plane.assign(stride * k.hblocks * 8, 0);
+        int coef[64];
+        for (int by = 0; by < k.hblocks; ++by)
+            for (int bx = 0; bx < k.wblocks; ++bx) {
+                const int16_t *cf = k.coefs.data() + ((size_t)by * k.wblocks + bx) * 64;
+                for (int i = 0; i < 64; ++i) coef[i] = cf[i] * qt[k.tq][i];
+                idct_islow(coef, k.plane.data() + (size_t)by * 8 * stride + (size_t)bx * 8, (int)stride);
+            }
+    }
     rgb.assign((size_t)W * H * 3, 0);
     if (ncomp == 1) {
         const size_t stride = (size_t)comp[0].wblocks * 8;

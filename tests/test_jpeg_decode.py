@@ -5,7 +5,9 @@ import io
 
 import numpy as np
 import pytest
-from PIL import Image
+from PIL import Image, ImageFile
+
+ImageFile.MAXBLOCK = 1 << 24  # Pillow's progressive / optimized encoder needs the whole file in one buffer
 
 from imageclust_amd import _lib
 
@@ -46,15 +48,48 @@ def test_grayscale_optimized_tables_and_restart_markers(tmp_path):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("size", [(64, 64), (224, 224), (37, 53), (300, 260), (17, 9), (1, 1), (481, 322)])
+@pytest.mark.parametrize("sub", [0, 1, 2])
+def test_progressive_matches_libjpeg_turbo(tmp_path, size, sub):
+    """SOF2: DC first/refine, AC first/refine with EOB runs, one scan per component (what OpenCV's IMRead decodes for
+    most product photos downloaded from the web)."""
+    for q in (30, 85, 100):
+        got, ref = roundtrip(tmp_path, Image.fromarray(picture(*size, seed=q + 1)), quality=q, subsampling=sub, progressive=True)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (size, sub, q)
+
+
+def test_progressive_grayscale_optimized_and_restarts(tmp_path):
+    im = Image.fromarray(picture(150, 211, 5))
+    got, ref = roundtrip(tmp_path, im.convert("L"), quality=70, progressive=True)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=60, progressive=True, optimize=True, subsampling=2)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=75, progressive=True, subsampling=2, restart_marker_blocks=5)
+    assert np.array_equal(got, ref)
+    got, ref = roundtrip(tmp_path, im, quality=75, progressive=True, subsampling=1, restart_marker_rows=2)
+    assert np.array_equal(got, ref)
+    # smooth content: long EOB runs and many all-zero blocks
+    flat = np.full((96, 160, 3), 200, np.uint8)
+    flat[20:40, 30:90] = (10, 60, 250)
+    got, ref = roundtrip(tmp_path, Image.fromarray(flat), quality=50, progressive=True)
+    assert np.array_equal(got, ref)
+
+
 def test_unsupported_and_corrupt_files(tmp_path):
     im = Image.fromarray(picture(64, 64, 2))
     buf = io.BytesIO()
-    im.save(buf, "JPEG", progressive=True)
-    p = tmp_path / "prog.jpg"
+    im.convert("CMYK").save(buf, "JPEG")
+    p = tmp_path / "cmyk.jpg"
     p.write_bytes(buf.getvalue())
     with pytest.raises(_lib.ICLError) as ei:
         _lib.decode_image_file(str(p))
     assert ei.value.code == _lib.ICL_ERR_UNSUPPORTED and "failed to read image" in str(ei.value)
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", progressive=True)
+    pq = tmp_path / "prog_trunc.jpg"
+    pq.write_bytes(buf.getvalue()[:150])
+    with pytest.raises(_lib.ICLError):
+        _lib.decode_image_file(str(pq))
     buf = io.BytesIO()
     im.save(buf, "JPEG")
     q = tmp_path / "trunc.jpg"
