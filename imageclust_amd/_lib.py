@@ -323,7 +323,7 @@ def calc_optimal_clusters(total, min_size, max_size):
 
 
 def decode_image_file(path):
-    """IMRead (embeddings.go:50) for baseline JPEG / binary PPM -> h x w x 3 u8 RGB."""
+    """IMRead (embeddings.go:50) for baseline or progressive JPEG / binary PPM -> h x w x 3 u8 RGB."""
     L = load()
     w, h = _i32(), _i32()
     rc = L.icl_decode_image_file(os.fsencode(path), None, 0, C.byref(w), C.byref(h))

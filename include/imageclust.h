@@ -75,10 +75,10 @@ int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes); /* host only, 
  * head: ICL_HEAD_POOLED or ICL_HEAD_DENSE0.  prec: ICL_PREC_*.  Batches internally (default 256). */
 int icl_embed_u8(icl_ctx *ctx, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
 int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head, int prec, float *d_out);
-/* One image file (baseline JPEG or binary PPM "P6"): decode, bilinear resize to 224x224
+/* One image file (baseline or progressive Huffman JPEG, or binary PPM "P6"): decode, bilinear resize to 224x224
  * (embeddings.go:69), then as icl_embed_u8 with n = 1, fp32. */
 int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
-/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline JPEG or binary PPM) to interleaved RGB.
+/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, or binary PPM) to interleaved RGB.
  * With rgb == NULL only *w / *h are returned.  cap_bytes must be >= w*h*3. */
 int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h);
 /* decode + cv::resize(INTER_LINEAR)-compatible resize to 224x224 (embeddings.go:50,69): out is 224*224*3 u8 RGB. */
