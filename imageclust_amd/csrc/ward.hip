@@ -1674,8 +1674,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     WB_TIMER(const unsigned long long tf0 = wall_clock64();)
     {
         constexpr int NW = (int)(sizeof(ward_state) / 4);
-        static_assert(NW <= WB_FIN_THREADS && sizeof(ward_state) % 4 == 0, "snapshot by one pass");
-        if (threadIdx.x < NW) reinterpret_cast<int *>(&ls)[threadIdx.x] = reinterpret_cast<const int *>(st)[threadIdx.x];
+        static_assert(sizeof(ward_state) % 4 == 0, "snapshot by dwords");
+        for (int q = threadIdx.x; q < NW; q += WB_FIN_THREADS) reinterpret_cast<int *>(&ls)[q] = reinterpret_cast<const int *>(st)[q];
         if (threadIdx.x == 0) npk = 0;
     }
     __syncthreads();
@@ -1683,22 +1683,25 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     const int nbp = ls.B.nb, t0 = ls.t, nlive0 = ls.nlive, target = ls.target;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- (1) validate: commit the longest prefix in which no pair of an earlier new cluster precedes the pick ----
-    // (wave 0: lane i*WB_K+j tests "a pair of c_i precedes p_j")
-    static_assert(WB_K * WB_K <= 64, "one lane per (i, j)");
+    // (wave 0: lane j holds the smallest row minimum of c_0..c_{j-1}, an exclusive prefix minimum by shuffles)
+    static_assert(WB_K <= 32, "one lane per pick");
     int J = nbp;
     if (wave == 0) {
-        const int vi = lane / WB_K, vj = lane % WB_K;
-        bool bad = false;
-        if (vi < vj && vj < nbp && lane < WB_K * WB_K) {
-            const unsigned long long k = ls.B.ckey[vi];
-            bad = k != ~0ull && __uint_as_float((unsigned)(k >> 32)) < ls.B.val[vj];
+        float cm = ICL_MAXF;
+        if (lane < nbp) {
+            const unsigned long long k = ls.B.ckey[lane];
+            if (k != ~0ull) cm = __uint_as_float((unsigned)(k >> 32));
         }
+        float pm = __shfl_up(cm, 1, 64); // exclusive
+        if (lane == 0) pm = ICL_MAXF;
+#pragma unroll
+        for (int off = 1; off < WB_K; off <<= 1) {
+            const float o = __shfl_up(pm, off, 64);
+            if (lane >= off) pm = fminf(pm, o);
+        }
+        const bool bad = lane >= 1 && lane < nbp && pm < ls.B.val[lane < WB_K ? lane : 0];
         const unsigned long long bm = __ballot(bad);
-        unsigned long long colm = 0; // lanes with vj == 1
-        for (int i2 = 0; i2 < WB_K; ++i2) colm |= 1ull << (i2 * WB_K + 1);
-        for (int j2 = 1; j2 < WB_K; ++j2) {
-            if (j2 < J && (bm & (colm << (j2 - 1)))) J = j2;
-        }
+        if (bm) J = __ffsll((long long)bm) - 1;
         if (lane == 0) sh[0] = J;
     }
     wb_map idm{-2, -1}, slm{-2, -1}; // id -> slot, slot -> id (wave 0 only)
@@ -1757,10 +1760,16 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         if (slm.key >= 0) slot_id[slm.key] = slm.val;
         {
             // slots whose CT4 column the update kernel has to re-make: the last write record of every touched slot
-            bool live = rec >= 0 && (d & 3) == 0;
+            bool later = false; // a later record writes the same slot
             for (int r2 = 1; r2 < 2 * WB_K; ++r2) {
                 const int o = __shfl_down(rec, r2, 64);
-                if (lane + r2 < 2 * WB_K && o == rec) live = false;
+                if (lane + r2 < 2 * WB_K && o == rec) later = true;
+            }
+            const bool live = rec >= 0 && !later && (d & 3) == 0;
+            const unsigned long long dm = __ballot(rec >= 0 && later);
+            if (lane == 0) {
+                sh[4] = (int)(unsigned)(dm & 0xffffffffull);
+                sh[5] = (int)(unsigned)(dm >> 32);
             }
             const unsigned long long lm = __ballot(live);
             if (live) st->B.dirty_slot[__popcll(lm & ((1ull << lane) - 1ull))] = rec;
@@ -1822,39 +1831,41 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                     const int mk = __shfl(idm.key, m, 64), mv = __shfl(idm.val, m, 64);
                     if (mk >= 0 && mk == myid) gs = mv;
                 }
-                if (lane < np) {
-                    const int j = lane;
-                    pk_sa[j] = ls.B.pre_sa[j];
-                    pk_sb[j] = ls.B.pre_sb[j];
-                    pk_sla[j] = gs;
-                    st->B.a[j] = ls.B.pre_row[j];
-                    st->B.b[j] = ls.B.pre_nn[j];
-                    st->B.sa[j] = ls.B.pre_sa[j];
-                    st->B.sb[j] = ls.B.pre_sb[j];
-                    st->B.val[j] = ls.B.pre_val[j];
-                    st->B.ckey[j] = ~0ull;
-                    rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
-                } else if (lane >= WB_K && lane < WB_K + np)
-                    pk_slb[lane - WB_K] = gs;
-                // does anything read a slot that this batch's commits write?  (rare: then values are forwarded)
+                // does anything read a slot that this batch's commits write?  (rare: then the general path runs)
                 bool need = false;
                 for (int r = 0; r < 2 * WB_K; ++r) {
                     const int o = __shfl(rec, r, 64);
-                    if (o >= 0 && o == gs) need = true;                      // a pick member of the next batch
+                    if (o >= 0 && o == gs) need = true;                                  // a pick member of the next batch
                     if (o >= 0 && o == frm && lane < WB_K && r <= 2 * lane) need = true; // a move's source
                 }
-                const bool fwd = __ballot(need) != 0;
-                if (lane == 0) {
-                    sh[3] = fwd ? 1 : 0;
-                    npk = np;
-                    st->B.nb = np;
-                    st->B.sum_live = ls.B.sum_live + (unsigned long long)(nlive0 - J);
-                    st->B.sum_live_nb = ls.B.sum_live_nb + (unsigned long long)(nlive0 - J) * np;
-                    st->B.epoch = ls.B.epoch + 1;
-                    st->B.pre_n = 0;
-                    st->B.ov_n = 0;
-                    st->B.pre_for_nb = -1;
-                    WB_TIMER(st->B.dbg2[0] += wall_clock64() - tf0;)
+                if (__ballot(need) != 0) {
+                    express = 0;
+                } else {
+                    if (lane < np) {
+                        const int j = lane;
+                        pk_sa[j] = ls.B.pre_sa[j];
+                        pk_sb[j] = ls.B.pre_sb[j];
+                        pk_sla[j] = gs;
+                        st->B.a[j] = ls.B.pre_row[j];
+                        st->B.b[j] = ls.B.pre_nn[j];
+                        st->B.sa[j] = ls.B.pre_sa[j];
+                        st->B.sb[j] = ls.B.pre_sb[j];
+                        st->B.val[j] = ls.B.pre_val[j];
+                        st->B.ckey[j] = ~0ull;
+                        rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
+                    } else if (lane >= WB_K && lane < WB_K + np)
+                        pk_slb[lane - WB_K] = gs;
+                    if (lane == 0) {
+                        npk = np;
+                        st->B.nb = np;
+                        st->B.sum_live = ls.B.sum_live + (unsigned long long)(nlive0 - J);
+                        st->B.sum_live_nb = ls.B.sum_live_nb + (unsigned long long)(nlive0 - J) * np;
+                        st->B.epoch = ls.B.epoch + 1;
+                        st->B.pre_n = 0;
+                        st->B.ov_n = 0;
+                        st->B.pre_for_nb = -1;
+                        WB_TIMER(st->B.dbg2[0] += wall_clock64() - tf0;)
+                    }
                 }
             }
         }
@@ -1868,74 +1879,77 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     WB_TIMER(if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;)
     if (sh[2]) {
         // one data phase, one k-group per thread: centroid images of the committed clusters (cnew_j into a's slot, THEN
-        // the compaction move, which may move it) and the merged centroids of the next batch (clustering.go:37-40);
-        // values written here are forwarded in registers, so there is no barrier and one round of loads
+        // the compaction move) and the merged centroids of the next batch (clustering.go:37-40), in chunks of 8
+        // commits / picks so that every load of a chunk is in flight at once.  The express path is only taken when
+        // nothing reads a slot written here (sh[3] == 0), so the chunks are independent; every old cnew row is read
+        // before any new one is written (same thread, same addresses: program order).
         const int np = npk;
         const int g = threadIdx.x;
+        const unsigned long long deadm = ((unsigned long long)(unsigned)sh[5] << 32) | (unsigned)sh[4]; // records overwritten later
         if (g < (d >> 2)) {
-            int rs[2 * WB_K]; // write records in program order: 2j = slot_a_j, 2j+1 = to_j (-1: none)
-            int cfr[WB_K];
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) {
-                rs[2 * j] = j < J ? cm_slot_a[j] : -1;
-                rs[2 * j + 1] = j < J ? cm_to[j] : -1;
-                cfr[j] = j < J ? cm_from[j] : -1;
-            }
-            int sla[WB_K], slb[WB_K];
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) {
-                sla[j] = j < np ? pk_sla[j] : -1;
-                slb[j] = j < np ? pk_slb[j] : -1;
-            }
-            float4 wv[2 * WB_K], av[WB_K], bv[WB_K];
-            const float4 z4 = make_float4(0, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) { // every load up front: they are independent
-                wv[2 * j] = j < J ? reinterpret_cast<const float4 *>(cnewK + j * cn_stride)[g] : z4;
-                wv[2 * j + 1] = cfr[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)cfr[j] * d)[g] : z4;
-                av[j] = sla[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)sla[j] * d)[g] : z4;
-                bv[j] = slb[j] >= 0 ? reinterpret_cast<const float4 *>(Crow + (int64_t)slb[j] * d)[g] : z4;
-            }
-            if (sh[3]) {
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) { // a move whose source was written earlier in this batch takes that value
-                if (cfr[j] >= 0) {
-#pragma unroll
-                    for (int r = 0; r <= 2 * j; ++r)
-                        if (rs[r] == cfr[j]) wv[2 * j + 1] = wv[r];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) { // pick members that live in a slot written by this batch: its final content
-#pragma unroll
-                for (int r = 0; r < 2 * WB_K; ++r) {
-                    if (rs[r] >= 0 && rs[r] == sla[j]) av[j] = wv[r];
-                    if (rs[r] >= 0 && rs[r] == slb[j]) bv[j] = wv[r];
-                }
-            }
-            }
-#pragma unroll
-            for (int r = 0; r < 2 * WB_K; ++r) {
-                bool dd = rs[r] < 0; // skipped when a later record overwrites the same slot
-#pragma unroll
-                for (int r2 = r + 1; r2 < 2 * WB_K; ++r2) dd |= rs[r2] == rs[r];
-                if (!dd) {
-                    reinterpret_cast<float4 *>(Crow + (int64_t)rs[r] * d)[g] = wv[r];
-                    if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, rs[r])) = wv[r];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) {
-                if (j < np) {
+            constexpr int CH = 8;
+            // Named values, not arrays: hipcc keeps float4 arrays of this size in scratch memory here, and without the
+            // fence it sinks every load next to its store (load, wait, store, ...), serialising the round trips.
+            auto chunk = [&](const int c0) {
+                const float *dummy = cnewK; // unused entries read a valid row: straight-line code
+                auto ld_w = [&](int r) { // write record r of this chunk: even = cnew_j -> slot_a_j, odd = content of from_j -> to_j
+                    const int j = c0 + (r >> 1);
+                    const float *src = dummy;
+                    if (j < J) {
+                        if (r & 1) {
+                            const int fr = cm_from[j];
+                            if (fr >= 0) src = Crow + (int64_t)fr * d;
+                        } else
+                            src = cnewK + j * cn_stride;
+                    }
+                    return reinterpret_cast<const float4 *>(src)[g];
+                };
+                auto st_w = [&](int r, const float4 &v) {
+                    const int j = c0 + (r >> 1);
+                    if (j >= J) return;
+                    const int sr = (r & 1) ? cm_to[j] : cm_slot_a[j];
+                    if (sr < 0 || ((deadm >> (2 * c0 + r)) & 1ull)) return;
+                    reinterpret_cast<float4 *>(Crow + (int64_t)sr * d)[g] = v;
+                    if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sr)) = v;
+                };
+                auto ld_p = [&](int q, bool second) { // centroid of a member of pick c0+q
+                    const int j = c0 + q;
+                    const float *src = dummy;
+                    if (j < np) src = Crow + (int64_t)(second ? pk_slb[j] : pk_sla[j]) * d;
+                    return reinterpret_cast<const float4 *>(src)[g];
+                };
+                auto st_p = [&](int q, const float4 &av, const float4 &bv) {
+                    const int j = c0 + q;
+                    if (j >= np) return;
                     const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
                     float4 o;
-                    { const float pa = fa * av[j].x; const float pb = fb * bv[j].x; const float sm = pa + pb; o.x = sm / fs; }
-                    { const float pa = fa * av[j].y; const float pb = fb * bv[j].y; const float sm = pa + pb; o.y = sm / fs; }
-                    { const float pa = fa * av[j].z; const float pb = fb * bv[j].z; const float sm = pa + pb; o.z = sm / fs; }
-                    { const float pa = fa * av[j].w; const float pb = fb * bv[j].w; const float sm = pa + pb; o.w = sm / fs; }
+                    { const float pa = fa * av.x; const float pb = fb * bv.x; const float sm = pa + pb; o.x = sm / fs; }
+                    { const float pa = fa * av.y; const float pb = fb * bv.y; const float sm = pa + pb; o.y = sm / fs; }
+                    { const float pa = fa * av.z; const float pb = fb * bv.z; const float sm = pa + pb; o.z = sm / fs; }
+                    { const float pa = fa * av.w; const float pb = fb * bv.w; const float sm = pa + pb; o.w = sm / fs; }
                     reinterpret_cast<float4 *>(cnewK + j * cn_stride)[g] = o;
-                }
-            }
+                };
+#define WB_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define WB_REP16(M) WB_REP8(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define WB_LDW(r) const float4 w##r = ld_w(r);
+#define WB_LDP(q) const float4 a##q = ld_p(q, false), b##q = ld_p(q, true);
+#define WB_STW(r) st_w(r, w##r);
+#define WB_STP(q) st_p(q, a##q, b##q);
+                WB_REP16(WB_LDW)
+                WB_REP8(WB_LDP)
+                asm volatile("" ::: "memory");
+                WB_REP16(WB_STW)
+                WB_REP8(WB_STP)
+#undef WB_LDW
+#undef WB_LDP
+#undef WB_STW
+#undef WB_STP
+            };
+            static_assert(CH == 8, "the chunk macros expand 8 commits / picks");
+            const int cmax = J > np ? J : np;
+            chunk(0);
+            if (WB_K > CH && CH < cmax) chunk(CH);
+            static_assert(WB_K <= 2 * CH, "two chunks");
         }
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
         return;
