@@ -30,9 +30,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_TIMER(stmt)
 #endif
 #ifndef WB_K
-#define WB_K 8 /* merges attempted per batched step */
+#define WB_K 8 /* merges attempted per batched step (16 was measured: same total, the preselection and the finish kernel grow as fast as the update shrinks) */
 #endif
-#define WB_R 24 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
+#define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
     int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
@@ -47,7 +47,8 @@ struct ward_batch_state {
     int32_t epoch, spec_pad[2];                   // speculative row re-minimisation by the spare workgroups
     int32_t spec_row[WB_R], spec_nn[WB_R], spec_done[WB_R];
     float spec_val[WB_R];
-    int32_t commits, steps, slow, pad;            // statistics
+    int32_t commits, steps, slow, general;        // statistics (general = steps that took the non-express finish path)
+    int32_t why[4];                               // ... because: 0 truncated batch, 1 preselection stale/empty, 2 new row first / forwarding chain
     unsigned long long sum_live, sum_live_nb;     // sum over steps of live clusters (x picks)
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long dbg[8], dbg_t0, dbg2[3];
@@ -442,7 +443,8 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->B.nb = 0;
         st->B.pre_n = 0;
         st->B.pre_for_nb = -1;
-        st->B.commits = st->B.steps = st->B.slow = 0;
+        st->B.commits = st->B.steps = st->B.slow = st->B.general = 0;
+        st->B.why[0] = st->B.why[1] = st->B.why[2] = st->B.why[3] = 0;
         st->B.sum_live = st->B.sum_live_nb = 0;
         st->B.epoch = 1;
         st->B.dirty_n = 0;
@@ -951,7 +953,7 @@ static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 
 // shuffles and appends a SENTINEL (a lower bound for everything it did not report); wave 0 then walks the <= 50
 // entries in ascending order and stops at the first sentinel, so whatever it saw before is exact.
 #define WB_MAXOV 8
-#define WB_WTOP 4
+#define WB_WTOP 5
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 {
 #pragma unroll
@@ -1820,9 +1822,16 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, off, 64));
-            if (cmin >= ls.B.pre_val[pn0 - 1]) {
+            // the preselected pairs are sorted: those whose value is <= every new row's minimum are certainly next
+            // (old rows win ties); a new-row pair may come before the others, which stay in the caches for later
+            int nsafe = 0;
+            {
+                const bool safe = lane < pn0 && ls.B.pre_val[lane < WB_K ? lane : 0] <= cmin;
+                nsafe = __popcll(__ballot(safe));
+            }
+            if (nsafe > 0) {
                 express = 1;
-                const int np = pn0 < target - t1 ? pn0 : target - t1;
+                const int np = nsafe < target - t1 ? nsafe : target - t1;
                 int myid = -1;
                 if (lane < np) myid = ls.B.pre_row[lane];
                 else if (lane >= WB_K && lane < WB_K + np) myid = ls.B.pre_nn[lane - WB_K];
@@ -1831,12 +1840,33 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                     const int mk = __shfl(idm.key, m, 64), mv = __shfl(idm.val, m, 64);
                     if (mk >= 0 && mk == myid) gs = mv;
                 }
-                // does anything read a slot that this batch's commits write?  (rare: then the general path runs)
+                // Where does each pick member's centroid come from?  Normally its slot's row; if the slot is written by
+                // this batch's commits, from that record's SOURCE instead (the old cnew row of a cluster just created,
+                // or the slot a compacted cluster is moved from), so that nothing has to be forwarded between threads'
+                // loads and stores.  Chains of such dependencies (rare) take the general path.
                 bool need = false;
-                for (int r = 0; r < 2 * WB_K; ++r) {
-                    const int o = __shfl(rec, r, 64);
-                    if (o >= 0 && o == gs) need = true;                                  // a pick member of the next batch
-                    if (o >= 0 && o == frm && lane < WB_K && r <= 2 * lane) need = true; // a move's source
+                int srcsel = gs; // >= 0: Crow slot; < 0: cnew row -1-j
+                {
+                    int last_r = -1;
+                    for (int r = 0; r < 2 * WB_K; ++r) {
+                        const int o = __shfl(rec, r, 64);
+                        if (o >= 0 && o == gs) last_r = r; // program order: the last record is the slot's final content
+                        if (o >= 0 && o == frm && lane < WB_K && r <= 2 * lane) need = true; // a move whose source was written earlier
+                    }
+                    const bool member = myid >= 0;
+                    const int pick = lane < WB_K ? lane : lane - WB_K;
+                    if (member && last_r >= 0) {
+                        const int j = last_r >> 1;
+                        if (!(last_r & 1)) { // the cluster created by commit j: its centroid is the OLD cnew row j
+                            srcsel = -1 - j;
+                            if (pick >= 8 && j < 8) need = true; // the second chunk runs after the first rewrote rows 0..7
+                        } else {             // moved by commit j from slot frm_j
+                            const int fj = __shfl(frm, j, 64);
+                            srcsel = fj;
+                            for (int r = 0; r < 2 * WB_K; ++r)
+                                if (__shfl(rec, r, 64) == fj) need = true; // its source is itself rewritten: give up
+                        }
+                    }
                 }
                 if (__ballot(need) != 0) {
                     express = 0;
@@ -1845,7 +1875,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         const int j = lane;
                         pk_sa[j] = ls.B.pre_sa[j];
                         pk_sb[j] = ls.B.pre_sb[j];
-                        pk_sla[j] = gs;
+                        pk_sla[j] = srcsel;
                         st->B.a[j] = ls.B.pre_row[j];
                         st->B.b[j] = ls.B.pre_nn[j];
                         st->B.sa[j] = ls.B.pre_sa[j];
@@ -1854,7 +1884,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.ckey[j] = ~0ull;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
                     } else if (lane >= WB_K && lane < WB_K + np)
-                        pk_slb[lane - WB_K] = gs;
+                        pk_slb[lane - WB_K] = srcsel;
                     if (lane == 0) {
                         npk = np;
                         st->B.nb = np;
@@ -1868,6 +1898,10 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                     }
                 }
             }
+        }
+        if (lane == 0 && !express && nbp > 0) { // why the general path: 0 truncated, 1 preselection stale/empty, 2 new row first / forwarding
+            const int why = J != nbp ? 0 : (ls.B.pre_for_nb != nbp || pn0 <= 0) ? 1 : 2;
+            st->B.why[why] = ls.B.why[why] + 1;
         }
         if (lane == 0) sh[2] = express;
     }
@@ -1915,7 +1949,10 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 auto ld_p = [&](int q, bool second) { // centroid of a member of pick c0+q
                     const int j = c0 + q;
                     const float *src = dummy;
-                    if (j < np) src = Crow + (int64_t)(second ? pk_slb[j] : pk_sla[j]) * d;
+                    if (j < np) {
+                        const int sel = second ? pk_slb[j] : pk_sla[j]; // >= 0: Crow slot; < 0: old cnew row -1-sel
+                        src = sel >= 0 ? Crow + (int64_t)sel * d : cnewK + (int64_t)(-1 - sel) * cn_stride;
+                    }
                     return reinterpret_cast<const float4 *>(src)[g];
                 };
                 auto st_p = [&](int q, const float4 &av, const float4 &bv) {
@@ -2035,6 +2072,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         }
     } else {
         {
+        if (lane == 0) st->B.general = ls.B.general + 1;
         // ---- (2) wave 0, fast path: candidates = rows just created (exact) + the preselected old-row pairs ----
         // (uniform scalar code; every lane computes the same thing from the snapshot)
         int crow[WB_K], cnn[WB_K];
@@ -2771,7 +2809,10 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t nmerge = hst.t;
     if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d\n", hst.t, hst.B.steps, hst.B.commits, hst.B.slow);
+        fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
+                hst.B.slow, hst.B.general);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d\n", hst.B.why[0], hst.B.why[1], hst.B.why[2]);
 #ifdef ICL_WARD_TIMERS
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
