@@ -30,7 +30,8 @@ struct icl_ward_ws; // ward.hip
 struct icl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr; // side stream: work forked beside `stream` inside captured graphs
+    hipStream_t stream2 = nullptr; // side stream: the second forward pass in flight (resnet.hip)
+    hipStream_t cur_stream = nullptr; // stream the convolution launches of the forward pass being enqueued go to (nullptr: stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mu;
     std::string err;

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <vector>
 
+#define ICL_MAX_LANES 4 /* forward passes in flight (ICL_EMBED_STREAMS) */
+
 struct conv_args {
     const void *X;      // [B][H][W][Cin]
     const void *Wt;     // [Cout][KH][KW][Cin]
@@ -534,8 +536,11 @@ struct icl_model {
     int nconv = 0;
     float *fcw = nullptr, *fcb = nullptr;
     // activation workspace
-    void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    float *pooled = nullptr;
+    void *buf[ICL_MAX_LANES][5] = {}; // one activation workspace per forward pass in flight
+    float *pooled[ICL_MAX_LANES] = {};
+    hipStream_t xstream[ICL_MAX_LANES] = {}; // lanes 2.. (lane 0 = ctx->stream, lane 1 = ctx->stream2)
+    hipEvent_t xjoin[ICL_MAX_LANES] = {};
+    int ws_lanes = 0;
     void *zero = nullptr; // 256 zero bytes: LDS-DMA source for padded taps
     float *ones = nullptr; // [2048] scale of the fused layers (their BN scale is folded into the weights)
     int ws_batch = 0, ws_prec = -1;
@@ -649,8 +654,15 @@ void icl_model_free(icl_ctx *ctx)
         for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift, c.wfused[0], c.wfused[1], (void *)c.shift_fused})
             if (p) (void)hipFree(p);
     }
-    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->buf[0], m->buf[1], m->buf[2], m->buf[3], m->buf[4], (void *)m->pooled, m->zero, (void *)m->ones})
+    for (void *p : {(void *)m->fcw, (void *)m->fcb, m->zero, (void *)m->ones})
         if (p) (void)hipFree(p);
+    for (int l = 0; l < ICL_MAX_LANES; ++l) {
+        for (void *b : m->buf[l])
+            if (b) (void)hipFree(b);
+        if (m->pooled[l]) (void)hipFree(m->pooled[l]);
+        if (m->xstream[l]) (void)hipStreamDestroy(m->xstream[l]);
+        if (m->xjoin[l]) (void)hipEventDestroy(m->xjoin[l]);
+    }
     delete m;
     ctx->model = nullptr;
 }
@@ -784,28 +796,41 @@ extern "C" int icl_model_load_onnx(icl_ctx *ctx, const char *path)
 // ------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------
-static int ensure_ws(icl_ctx *ctx, int batch, int prec)
+static int ensure_ws(icl_ctx *ctx, int batch, int prec, int lanes)
 {
     icl_model *m = ctx->model;
-    if (m->ws_batch >= batch && m->ws_prec == prec) return ICL_OK;
+    if (m->ws_batch >= batch && m->ws_prec == prec && m->ws_lanes >= lanes) return ICL_OK;
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &b : m->buf)
-        if (b) {
-            (void)hipFree(b);
-            b = nullptr;
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    for (int l = 2; l < lanes; ++l)
+        if (!m->xstream[l]) {
+            ICL_HIP(ctx, hipStreamCreateWithFlags(&m->xstream[l], hipStreamNonBlocking));
+            ICL_HIP(ctx, hipEventCreateWithFlags(&m->xjoin[l], hipEventDisableTiming));
         }
-    if (m->pooled) (void)hipFree(m->pooled);
-    m->pooled = nullptr;
+    for (int l = 0; l < ICL_MAX_LANES; ++l) {
+        if (m->xstream[l]) ICL_HIP(ctx, hipStreamSynchronize(m->xstream[l]));
+        for (auto &b : m->buf[l])
+            if (b) {
+                (void)hipFree(b);
+                b = nullptr;
+            }
+        if (m->pooled[l]) (void)hipFree(m->pooled[l]);
+        m->pooled[l] = nullptr;
+    }
     m->ws_batch = 0;
+    m->ws_lanes = 0;
     const size_t es = prec == ICL_PREC_BF16 ? 2 : 4;
     const size_t act = (size_t)batch * 802816 * es; // 112*112*64 == 56*56*256: the largest activation
-    for (auto &b : m->buf) {
-        hipError_t e = hipMalloc(&b, act);
-        if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "activation workspace (%zu B): %s", act, hipGetErrorString(e));
+    for (int l = 0; l < lanes; ++l) {
+        for (auto &b : m->buf[l]) {
+            hipError_t e = hipMalloc(&b, act);
+            if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "activation workspace (%zu B): %s", act, hipGetErrorString(e));
+        }
+        ICL_HIP(ctx, hipMalloc((void **)&m->pooled[l], (size_t)batch * ICL_FEAT_DIM * 4));
     }
-    ICL_HIP(ctx, hipMalloc((void **)&m->pooled, (size_t)batch * ICL_FEAT_DIM * 4));
     m->ws_batch = batch;
     m->ws_prec = prec;
+    m->ws_lanes = lanes;
     return ICL_OK;
 }
 
@@ -819,7 +844,7 @@ static void launch_conv_variant(icl_ctx *ctx, conv_args &a, int nst_lds)
         attr_done = true;
     }
     a.gy = a.Cout / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, DUAL, NST, EARLY>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<BN>(nst_lds), ctx->stream,
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, DUAL, NST, EARLY>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<BN>(nst_lds), ctx->cur_stream ? ctx->cur_stream : ctx->stream,
                        a);
 }
 
@@ -1008,12 +1033,14 @@ static int launch_conv_fused_ds(icl_ctx *ctx, int prec, const conv_layer &c3, co
 }
 
 template <typename T>
-static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, int head, float *d_out)
+static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, int head, float *d_out, int lane, hipStream_t strm)
 {
     typedef typename T::elem elem;
     icl_model *m = ctx->model;
+    ctx->cur_stream = strm;
     const int grid = 256 * 8;
-    elem *x = (elem *)m->buf[0], *t1 = (elem *)m->buf[1], *t2 = (elem *)m->buf[2], *ds = (elem *)m->buf[3], *y = (elem *)m->buf[4];
+    elem *x = (elem *)m->buf[lane][0], *t1 = (elem *)m->buf[lane][1], *t2 = (elem *)m->buf[lane][2], *ds = (elem *)m->buf[lane][3],
+         *y = (elem *)m->buf[lane][4];
     {
         static bool attr_done = false;
         if (!attr_done) {
@@ -1027,11 +1054,11 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
         a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
         a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
         icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
-        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3((unsigned)a.gx), dim3(256), stem_lds_bytes<T>(), ctx->stream, d_img, a);
+        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3((unsigned)a.gx), dim3(256), stem_lds_bytes<T>(), strm, d_img, a);
     }
     {
         icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
-        hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, y, B, 112, 64, x);
+        hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, strm, y, B, 112, 64, x);
     }
     int ci = 1;
     while (ci < m->nconv) {
@@ -1046,16 +1073,16 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
         std::swap(x, y);
         ci += has_ds ? 4 : 3;
     }
-    float *pooled = head == ICL_HEAD_POOLED ? d_out : m->pooled;
+    float *pooled = head == ICL_HEAD_POOLED ? d_out : m->pooled[lane];
     {
         icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * 49.0 * 2048.0 * sizeof(elem));
-        hipLaunchKernelGGL((avgpool_kernel<T>), dim3((unsigned)icl_ceil_div((int64_t)B * 2048, 256)), dim3(256), 0, ctx->stream, x, B, 49,
+        hipLaunchKernelGGL((avgpool_kernel<T>), dim3((unsigned)icl_ceil_div((int64_t)B * 2048, 256)), dim3(256), 0, strm, x, B, 49,
                            ICL_FEAT_DIM, pooled, (int64_t)ICL_FEAT_DIM);
     }
     if (head == ICL_HEAD_DENSE0) {
         icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 2.0 * B * 2048.0 * 1000.0, 0.0);
         hipLaunchKernelGGL(fc_kernel, dim3((unsigned)std::min<int64_t>(icl_ceil_div((int64_t)B * ICL_FC_OUT, 4), 4096)), dim3(256), 0,
-                           ctx->stream, pooled, m->fcw, m->fcb, B, ICL_FEAT_DIM, ICL_FC_OUT, d_out);
+                           strm, pooled, m->fcw, m->fcb, B, ICL_FEAT_DIM, ICL_FC_OUT, d_out);
     }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
@@ -1068,16 +1095,39 @@ static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int h
     if (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) return icl_fail(ctx, ICL_ERR_ARG, "prec must be ICL_PREC_FP32 or ICL_PREC_BF16");
     if (n == 0) return ICL_OK;
     const int batch = (int)std::min<int64_t>(ctx->batch, n);
-    ICL_TRY(ensure_ws(ctx, batch, prec));
+    // Two forward passes in flight on two streams (each its own activation workspace): batches stay at the configured
+    // size, and the launches of one pass fill the CUs the other leaves idle (late stages have few tiles, HBM-bound
+    // layers meet MFMA-bound ones).  Per-kernel profiling brackets launches with events on the main stream: one lane.
+    static const int lanes_env = [] {
+        const char *e = getenv("ICL_EMBED_STREAMS");
+        return e ? atoi(e) : 2;
+    }();
+    int lanes = (ctx->prof_mask || lanes_env < 2) ? 1 : std::min(lanes_env, ICL_MAX_LANES);
+    lanes = (int)std::min<int64_t>(lanes, (n + batch - 1) / batch);
+    ICL_TRY(ensure_ws(ctx, batch, prec, lanes));
     hipEvent_t e0, e1;
     ICL_HIP(ctx, hipEventCreate(&e0));
     ICL_HIP(ctx, hipEventCreate(&e1));
     ICL_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int64_t i = 0; i < n; i += batch) {
+    auto lane_stream = [&](int l) { return l == 0 ? ctx->stream : l == 1 ? ctx->stream2 : ctx->model->xstream[l]; };
+    if (lanes > 1) { // fork: the side streams start after everything already queued on the main stream
+        ICL_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int l = 1; l < lanes; ++l) ICL_HIP(ctx, hipStreamWaitEvent(lane_stream(l), ctx->ev_fork, 0));
+    }
+    int64_t bi = 0;
+    for (int64_t i = 0; i < n; i += batch, ++bi) {
         const int B = (int)std::min<int64_t>(batch, n - i);
-        const int rc = prec == ICL_PREC_BF16 ? forward_batch<BF16>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head)
-                                             : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head);
+        const int lane = (int)(bi % lanes);
+        hipStream_t strm = lane_stream(lane);
+        const int rc = prec == ICL_PREC_BF16 ? forward_batch<BF16>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm)
+                                             : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm);
         if (rc) return rc;
+    }
+    ctx->cur_stream = nullptr;
+    for (int l = 1; l < lanes; ++l) { // join
+        hipEvent_t ej = l == 1 ? ctx->ev_join : ctx->model->xjoin[l];
+        ICL_HIP(ctx, hipEventRecord(ej, lane_stream(l)));
+        ICL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ej, 0));
     }
     ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
