@@ -209,10 +209,10 @@ def main():
         # itself cannot run under the profiler.
         traffic = traffic_upd = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v2.json")) as f:
                 pmc = json.load(f)
             traffic = round(pmc["conv_igemm_kernel<BF16,128>"]["hbm_bytes_per_launch"], 0)
-            traffic_upd = round(pmc["ward_update_exact_kernel"]["hbm_bytes_per_launch"], 0)
+            traffic_upd = round(pmc["ward_update_batch_kernel"]["hbm_bytes_per_launch"], 0)
         except Exception:
             pass
         conv_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
@@ -232,7 +232,10 @@ def main():
             exact = args.update == "exact"
             ward_roof = {"bound": "hbm", "kernel": "ward_update_batch_kernel" if exact else "ward_update_lw_kernel",
                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if not exact else None, "launches": upd["launches"],
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
+                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE over the first 40 launches (n_live ~ 9850: 81 MB algorithmic), "
+                                         "profiles/r01_pmc_traffic_v2.json",
+                         "launches": upd["launches"],
                          "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
                          "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),
                          "merges_per_working_launch": round(ws["merges"] / max(ws["steps"], 1), 2),
