@@ -1391,8 +1391,11 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     // blocks WB_R+1 .. WB_R+WB_NH: "virtual slots" (lane i = tentative cluster c_i, column = its new centroid)
     const bool virt = blockIdx.x <= WB_R + WB_NH;
     const int64_t mb = (int64_t)blockIdx.x - (WB_R + 1 + WB_NH);
-    const int64_t mblk = virt ? 0 : mb / WB_NH;
-    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)(mb % WB_NH); // which WB_KC chains this workgroup runs
+    // workgroups are dealt to the 8 XCDs round-robin: the WB_NH workgroups of a slot block are spaced a multiple of 8
+    // apart so that they share an L2 and the second reader of a centroid column hits it
+    const int64_t bstride = (S / 64 + 7) / 8 * 8;
+    const int64_t mblk = virt ? 0 : mb % bstride;
+    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)(mb / bstride); // which WB_KC chains this workgroup runs
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
     int pa[WB_K], pb[WB_K], psc[WB_K];
@@ -2715,7 +2718,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); // + the preselection's static arrays
             wb_attr = true;
         }
-        const unsigned wb_blocks = (unsigned)(w->S / 64) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
+        const unsigned wb_blocks = (unsigned)((w->S / 64 + 7) / 8 * 8) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st);
