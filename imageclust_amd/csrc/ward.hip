@@ -1391,11 +1391,12 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
     // blocks WB_R+1 .. WB_R+WB_NH: "virtual slots" (lane i = tentative cluster c_i, column = its new centroid)
     const bool virt = blockIdx.x <= WB_R + WB_NH;
     const int64_t mb = (int64_t)blockIdx.x - (WB_R + 1 + WB_NH);
-    // workgroups are dealt to the 8 XCDs round-robin: the WB_NH workgroups of a slot block are spaced a multiple of 8
-    // apart so that they share an L2 and the second reader of a centroid column hits it
-    const int64_t bstride = (S / 64 + 7) / 8 * 8;
-    const int64_t mblk = virt ? 0 : mb % bstride;
-    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)(mb / bstride); // which WB_KC chains this workgroup runs
+    // workgroups are dealt to the 8 XCDs round-robin in dispatch order: the WB_NH workgroups of a slot block sit exactly
+    // 8 apart (groups of 8 blocks, then their partners), so they share an L2 and run at the same time -- the second
+    // reader of a centroid column hits the L2 instead of fetching it again (at large N the centroid store is far bigger
+    // than the Infinity Cache and the kernel is bound by that traffic)
+    const int64_t mblk = virt ? 0 : (mb / (8 * WB_NH)) * 8 + (mb & 7);
+    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)((mb >> 3) % WB_NH); // which WB_KC chains this workgroup runs
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
     int pa[WB_K], pb[WB_K], psc[WB_K];
