@@ -1406,6 +1406,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         pb[j] = st->B.b[j];
         psc[j] = st->B.sa[j] + st->B.sb[j];
     }
+    if (!virt && mblk * 64 >= S) return; // grid padding (the block count is rounded up to a multiple of 8): nothing to read
     const int64_t slot = virt ? lane : mblk * 64 + lane;
     const int xraw = virt ? -1 : slot_id[slot];
     const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
