@@ -33,6 +33,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_K 8 /* merges attempted per batched step (16 was measured: same total, the preselection and the finish kernel grow as fast as the update shrinks) */
 #endif
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
+#define WB_RM 4 /* rows each of them takes (matches wg, wg + WB_R, ...): hub clusters leave hundreds of rows dirty */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
     int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
@@ -45,12 +46,14 @@ struct ward_batch_state {
     float ov_val[8];
     int32_t dirty_n, dirty_slot[2 * WB_K];        // slots whose CT4 column (k-groups >= 2 stages) still has to be re-made from Crow
     int32_t epoch, spec_pad[2];                   // speculative row re-minimisation by the spare workgroups
-    int32_t spec_row[WB_R], spec_nn[WB_R], spec_done[WB_R];
-    float spec_val[WB_R];
+    int32_t spec_row[WB_R * WB_RM], spec_nn[WB_R * WB_RM], spec_done[WB_R]; // entry m*WB_R + wg: m-th row of spare workgroup wg
+    float spec_val[WB_R * WB_RM];
     int32_t commits, steps, slow, general;        // statistics (general = steps that took the non-express finish path)
     int32_t why[4];                               // ... because: 0 truncated batch, 1 preselection stale/empty, 2 new row first / forwarding chain
     unsigned long long sum_live, sum_live_nb;     // sum over steps of live clusters (x picks)
+    unsigned long long sum_dep;                   // sum over steps of rows whose cached partner is a member of the batch
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
+    unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
 };
 
@@ -446,11 +449,12 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->B.commits = st->B.steps = st->B.slow = st->B.general = 0;
         st->B.why[0] = st->B.why[1] = st->B.why[2] = st->B.why[3] = 0;
         st->B.sum_live = st->B.sum_live_nb = 0;
+        st->B.sum_dep = 0;
         st->B.epoch = 1;
         st->B.dirty_n = 0;
         st->B.ov_n = 0;
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = 0;
-        for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = ~0ull;
+        for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
     }
@@ -1027,7 +1031,7 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
 {
     __shared__ int excl[2 * WB_K];
     __shared__ int wcnt[16];
-    __shared__ int mine[2];
+    __shared__ int mine[WB_RM];
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
     if (nb <= 0 || t0 + nb >= st->target) return;
@@ -1035,7 +1039,6 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
         const int j = threadIdx.x >> 1;
         excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
     }
-    if (threadIdx.x == 0) mine[0] = -1;
     __syncthreads();
     int ex[2 * WB_K];
 #pragma unroll
@@ -1044,10 +1047,9 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
     // enumerate: thread-strided over int4 groups of rownn; a thread's matches keep their row order
     const int64_t nvec = (n + t0 + 3) >> 2;
     int cnt = 0;
-    unsigned long long hits = 0; // bit (4*iter + e) for up to 16 iterations
+    int hrow0 = -1, hrow1 = -1, hrow2 = -1, hrow3 = -1; // the thread's first four matches, in row order (any n)
     {
-        int it = 0;
-        for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x, ++it) {
+        for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x) {
             const int4 nn4 = reinterpret_cast<const int4 *>(rownn)[q];
             const int nnv[4] = {nn4.x, nn4.y, nn4.z, nn4.w};
 #pragma unroll
@@ -1061,8 +1063,11 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
 #pragma unroll
                     for (int z = 0; z < 2 * WB_K; ++z) self |= r == ex[z];
                     if (!self && rowmin[r] < ICL_MAXF) { // alive rows only (dead rows hold MaxFloat32)
+                        if (cnt == 0) hrow0 = r;
+                        else if (cnt == 1) hrow1 = r;
+                        else if (cnt == 2) hrow2 = r;
+                        else if (cnt == 3) hrow3 = r;
                         ++cnt;
-                        if (it < 16) hits |= 1ull << (4 * it + e);
                     }
                 }
             }
@@ -1080,31 +1085,35 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
     int base = 0;
     for (int w2 = 0; w2 < wave; ++w2) base += wcnt[w2];
     const int first = base + inc - cnt;
-    // the match with global index wg is mine (concurrent write-backs by the preselection may make two workgroups
-    // disagree on the enumeration: every workgroup therefore publishes the row it actually scanned)
-    if (cnt > 0 && first <= wg && wg < first + cnt) {
-        int idx = first, it = 0;
-        for (int64_t q = threadIdx.x; q < nvec && it < 16; q += blockDim.x, ++it) {
+    if (wg == 0 && threadIdx.x == blockDim.x - 1) st->B.sum_dep += (unsigned long long)(first + cnt); // statistics: rows depending on the batch
+    // the matches with global index wg, wg + WB_R, ... are mine (concurrent write-backs by the preselection may make two
+    // workgroups disagree on the enumeration: every workgroup therefore publishes the rows it actually scanned)
+    if (threadIdx.x < WB_RM) mine[threadIdx.x] = -1;
+    __syncthreads();
+    {
+        const int hr[4] = {hrow0, hrow1, hrow2, hrow3};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((hits >> (4 * it + e)) & 1ull) {
-                    if (idx == wg) mine[0] = (int)(q * 4 + e);
-                    ++idx;
-                }
+        for (int z = 0; z < 4; ++z) { // a thread's fifth and later matches are left to the lazy path
+            const int idx = first + z;
+            if (z < cnt && idx >= wg && (idx - wg) % WB_R == 0 && (idx - wg) / WB_R < WB_RM) mine[(idx - wg) / WB_R] = hr[z];
         }
     }
     __syncthreads();
-    const int r = mine[0];
-    float rv = ICL_MAXF;
-    int ri = -1;
-    if (r >= 0) {
-        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri);
-        block_argmin(rv, ri, sv, si);
+    for (int m = 0; m < WB_RM; ++m) {
+        const int r = mine[m];
+        float rv = ICL_MAXF;
+        int ri = -1;
+        if (r >= 0) {
+            scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri);
+            block_argmin(rv, ri, sv, si);
+        }
+        if (threadIdx.x == 0) {
+            st->B.spec_row[m * WB_R + wg] = r;
+            st->B.spec_val[m * WB_R + wg] = rv;
+            st->B.spec_nn[m * WB_R + wg] = ri;
+        }
     }
     if (threadIdx.x == 0) {
-        st->B.spec_row[wg] = r;
-        st->B.spec_val[wg] = rv;
-        st->B.spec_nn[wg] = ri;
         __threadfence();
         __hip_atomic_store(&st->B.spec_done[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1214,8 +1223,14 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
     WB_TIMER(if (threadIdx.x == 0) st->B.dbg[7] += wall_clock64() - st->B.dbg_t0;)
     int npick = 0, nov = 0, nresc = 0;
     const int epoch = st->B.epoch;
-    int spl_row = -1, spl_nn = -1, spl_n = -1; // lane l: result of spare workgroup l (loaded on first use)
-    float spl_val = ICL_MAXF;
+    int spl_row[WB_RM], spl_nn[WB_RM], spl_n = -1; // lane l: results of spare workgroup l (loaded on first use)
+    float spl_val[WB_RM];
+#pragma unroll
+    for (int m = 0; m < WB_RM; ++m) {
+        spl_row[m] = -1;
+        spl_nn[m] = -1;
+        spl_val[m] = ICL_MAXF;
+    }
     int pm[2 * WB_K]; // members of the picks made here
 #pragma unroll
     for (int z = 0; z < 2 * WB_K; ++z) pm[z] = -1;
@@ -1255,16 +1270,28 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
                         }
                         spl_n = __all(ok) ? WB_R : 0;
                         if (spl_n && lane < WB_R) {
-                            spl_row = __hip_atomic_load(&st->B.spec_row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            spl_nn = __hip_atomic_load(&st->B.spec_nn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            spl_val = __hip_atomic_load(&st->B.spec_val[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int m = 0; m < WB_RM; ++m) {
+                                spl_row[m] = __hip_atomic_load(&st->B.spec_row[m * WB_R + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                spl_nn[m] = __hip_atomic_load(&st->B.spec_nn[m * WB_R + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                spl_val[m] = __hip_atomic_load(&st->B.spec_val[m * WB_R + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
-                    const unsigned long long hm = __ballot(lane < spl_n && spl_row == r);
+                    unsigned long long hm = 0;
+                    int sn = -1;
+                    float sval = ICL_MAXF;
+#pragma unroll
+                    for (int m = 0; m < WB_RM; ++m) {
+                        const unsigned long long h2 = __ballot(lane < spl_n && spl_row[m] == r);
+                        if (h2 && !hm) {
+                            hm = h2;
+                            const int idx = __ffsll((long long)h2) - 1;
+                            sn = __shfl(spl_nn[m], idx, 64);
+                            sval = __shfl(spl_val[m], idx, 64);
+                        }
+                    }
                     if (hm) {
-                        const int idx = __ffsll((long long)hm) - 1;
-                        const int sn = __shfl(spl_nn, idx, 64);
-                        const float sval = __shfl(spl_val, idx, 64);
                         if (lane == src) {
                             if (sn < 0) {
                                 key = ~0ull;
@@ -1344,6 +1371,7 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
         }
     }
     if (threadIdx.x == 0) {
+        st->B.why[3] += nresc - nov; // re-minimisations of rows whose partner had really died (statistics)
         st->B.pre_n = npick;
         st->B.ov_n = nov;
         st->B.pre_for_nb = nb;
@@ -1462,6 +1490,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         sx = x >= 0 ? asz[x] : 0;
     }
     unsigned okmask = 0;
+    bool survives = false;
     {
         bool alive = x >= 0 && sx > 0;
 #pragma unroll
@@ -1475,6 +1504,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
                 }
             }
         }
+        survives = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
     }
     okmask >>= half * WB_KC; // this workgroup's chains
     const int nd = virt ? 0 : dirty_n0;
@@ -1621,12 +1651,19 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
             Dtri[rowoff[c] + x] = val;
             if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
         }
+        // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the validation
+        // needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's cache after a full
+        // commit (otherwise the row would be born dirty whenever its partner is merged by a later pick)
+        unsigned long long key2 = survives ? key : ~0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_down(key, off, 64);
             key = o < key ? o : key;
+            const unsigned long long o2 = __shfl_down(key2, off, 64);
+            key2 = o2 < key2 ? o2 : key2;
         }
         if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
+        if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
         WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
@@ -1785,7 +1822,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         if (lane < J) {
             const int j = lane;
             const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
-            const unsigned long long key = ls.B.ckey[j];
+            const unsigned long long key = J == nbp ? ls.B.ckey2[j] : ls.B.ckey[j]; // full commit: the batch's members are all gone
             merges[3 * (t0 + j)] = a;
             merges[3 * (t0 + j) + 1] = b;
             merges[3 * (t0 + j) + 2] = (int)__float_as_uint(ls.B.val[j]); // the pair's Ward distance: the dendrogram height
@@ -1801,9 +1838,15 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
             rownn[ls.B.ov_row[lane]] = ls.B.ov_nn[lane];
         }
-        if (J == nbp && lane < WB_R && ls.B.spec_done[lane] == ls.B.epoch && ls.B.spec_row[lane] >= 0) { // ... and by the spare workgroups
-            rowmin[ls.B.spec_row[lane]] = ls.B.spec_val[lane];
-            rownn[ls.B.spec_row[lane]] = ls.B.spec_nn[lane];
+        if (J == nbp && lane < WB_R && ls.B.spec_done[lane] == ls.B.epoch) { // ... and by the spare workgroups
+#pragma unroll
+            for (int m = 0; m < WB_RM; ++m) {
+                const int sr = ls.B.spec_row[m * WB_R + lane];
+                if (sr >= 0) {
+                    rowmin[sr] = ls.B.spec_val[m * WB_R + lane];
+                    rownn[sr] = ls.B.spec_nn[m * WB_R + lane];
+                }
+            }
         }
         if (lane == 0) {
             st->nlive = nlive0 - J;
@@ -1886,7 +1929,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.sa[j] = ls.B.pre_sa[j];
                         st->B.sb[j] = ls.B.pre_sb[j];
                         st->B.val[j] = ls.B.pre_val[j];
-                        st->B.ckey[j] = ~0ull;
+                        st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
                     } else if (lane >= WB_K && lane < WB_K + np)
                         pk_slb[lane - WB_K] = srcsel;
@@ -2296,7 +2339,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             st->B.sa[j] = pk_sa[j];
             st->B.sb[j] = pk_sb[j];
             st->B.val[j] = pk_v[j];
-            st->B.ckey[j] = ~0ull;
+            st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
             rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
         }
         if (j == 0) {
@@ -2817,7 +2860,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
                 hst.B.slow, hst.B.general);
     if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d\n", hst.B.why[0], hst.B.why[1], hst.B.why[2]);
+        fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
 #ifdef ICL_WARD_TIMERS
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
