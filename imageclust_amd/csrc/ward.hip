@@ -932,7 +932,9 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
 // simply stay in the caches.  Row c_j is computed against the clusters alive at ITS time: members of p_0..p_j are
 // excluded, c_0..c_{j-1} are included (as "virtual slots" whose columns are the new centroids).
 // ============================================================================================================
-#define WB_P 6
+#ifndef WB_P
+#define WB_P 4                        /* producer waves: with 16 k-groups per stage the workgroup needs 64 KB of LDS and 128 VGPRs, so two fit a CU */
+#endif
 #ifndef WB_PRING
 #define WB_PRING 0                    /* 1: producers square the differences (ring of p per chain): measured SLOWER (update 50 us vs 37 us per launch, the ds_write_b128 path saturates); 0: chain waves do (ring of x) */
 #endif
@@ -1380,7 +1382,7 @@ __device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz,
 }
 
 // update for a batch: rows of up to WB_K tentative clusters in one pass over the centroids.
-__global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+__global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       int64_t cn_stride,
                                                                       const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
@@ -1524,7 +1526,7 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_kernel(int d, in
         return;
     }
     float4 *cn4 = wb_lds + RING_F4;
-    const int cnl = dqp + WB_PAD_G; // float4s per centroid image in LDS
+    const int cnl = dqp; // float4s per centroid image in LDS (only stages < dqp / WB_SG are ever read)
     const int nch = nb - half * WB_KC < WB_KC ? nb - half * WB_KC : WB_KC; // chains run here
     for (int j = 0; j < nch; ++j)
         for (int g = threadIdx.x; g < cnl; g += WB_THREADS)
@@ -2756,7 +2758,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // dependent (between T/WB_K and T).  Steps are enqueued in chunks of GRAPH_STEPS; the state is read back after
         // each chunk, one chunk behind the launches so the queue never drains.
         const int dqb = (int)wb_groups(d);
-        const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * (dqb + WB_PAD_G) * 16;
+        const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * dqb * 16;
         if (wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
         static bool wb_attr = false;
         if (!wb_attr) {
