@@ -848,51 +848,32 @@ static void launch_conv_variant(icl_ctx *ctx, conv_args &a, int nst_lds)
                        a);
 }
 
-// Tile / pipeline choice per layer (B=256 shapes of ResNet50, measured with scratch/layer_report.py):
-//  * K-heavy layers (3x3, K >= 1024) are MFMA bound: 128x128 tile, 2 stages (64 KB LDS, 2 workgroups per CU);
-//  * layers with few k-steps per tile are bound by the bytes a CU keeps in flight: 128x64 tile with a 3-stage ring
-//    (72 KB LDS, still 2 workgroups per CU, 2 k-steps in flight each).
-static int conv_mode_env()
-{
-    static const int v = [] {
-        const char *e = getenv("ICL_CONV_MODE");
-        return e ? atoi(e) : -1;
-    }();
-    return v;
-}
-
+// Tile / pipeline choice (B=256 shapes of ResNet50, measured with scratch/layer_report.py): 128x128 tile (128x64 for
+// Cout = 64), two stages, two workgroups per CU, everything requested up front (EARLY).  ICL_CONV_MODE=0 selects the
+// plain two-stage loop (one k-step staged ahead) for A/B comparisons.  Deeper rings (three / four stages, one workgroup
+// per CU), 128x64 tiles for the 128-wide layers, weights in registers and dedicated loader waves were all measured
+// slower.
 template <typename T>
 static int launch_conv_t(icl_ctx *ctx, conv_args a)
 {
     a.gx = (int)icl_ceil_div(a.M, CV_BM);
     const int nk = a.K / T::BK;
-    const int mode = conv_mode_env();
-    // deep = 128x64 tile, 3 stages.  Default: layers with 2..8 k-steps whose grid still fills the chip with 64-wide tiles
-    bool deep = false;
-    if (mode == 1) deep = nk >= 2;
-    icl_prof_scope ps(ctx, (a.Cout % 128 == 0 && !deep) ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
-    const bool sel = nk >= 2 && nk <= 8;
-    int early_max = 1 << 30; // EARLY (everything requested up front, refill after the MFMAs) for tiles of up to this many k-steps
-    if (mode >= 100) early_max = mode - 100;
-    const bool early = nk <= early_max;
+    static const bool early = [] {
+        const char *e = getenv("ICL_CONV_MODE");
+        return !(e && atoi(e) == 0);
+    }();
+    const bool wide = a.Cout % 128 == 0;
+    icl_prof_scope ps(ctx, wide ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    const int nst = nk > 1 ? 2 : 1; // single-k-step layers need one stage only -> more workgroups per CU
     if (a.X2) {
-        if (deep) launch_conv_variant<T, 64, true, 3>(ctx, a, 3);
-        else if (mode == 2 && sel) launch_conv_variant<T, 128, true, 3>(ctx, a, 3);
-        else if (mode == 3 && sel) launch_conv_variant<T, 64, true, 2>(ctx, a, 2);
-        else if (early) launch_conv_variant<T, 128, true, 2, true>(ctx, a, 2);
+        if (early) launch_conv_variant<T, 128, true, 2, true>(ctx, a, 2);
         else launch_conv_variant<T, 128, true, 2>(ctx, a, 2);
-    } else if (a.Cout % 128 == 0 && !deep) {
-        if (mode == 2 && sel) launch_conv_variant<T, 128, false, 3>(ctx, a, 3);
-        else if (mode == 3 && sel) launch_conv_variant<T, 64, false, 2>(ctx, a, 2);
-        else if (mode == 4 && nk >= 16) launch_conv_variant<T, 128, false, 4>(ctx, a, 4);
-        else if (mode == 5 && nk >= 16) launch_conv_variant<T, 128, false, 3>(ctx, a, 3);
-        else if (early) launch_conv_variant<T, 128, false, 2, true>(ctx, a, nk > 1 ? 2 : 1);
-        else launch_conv_variant<T, 128, false, 2>(ctx, a, nk > 1 ? 2 : 1); // single-k-step layers need one stage only -> more workgroups per CU
-    } else if (deep) {
-        launch_conv_variant<T, 64, false, 3>(ctx, a, 3);
+    } else if (wide) {
+        if (early) launch_conv_variant<T, 128, false, 2, true>(ctx, a, nst);
+        else launch_conv_variant<T, 128, false, 2>(ctx, a, nst);
     } else {
-        if (early) launch_conv_variant<T, 64, false, 2, true>(ctx, a, nk > 1 ? 2 : 1);
-        else launch_conv_variant<T, 64, false, 2>(ctx, a, nk > 1 ? 2 : 1);
+        if (early) launch_conv_variant<T, 64, false, 2, true>(ctx, a, nst);
+        else launch_conv_variant<T, 64, false, 2>(ctx, a, nst);
     }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
