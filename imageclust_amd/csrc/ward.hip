@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void scan_row_ex(const float *__restrict__ row, int64
 // once it commits.  Every spare workgroup enumerates them in the same deterministic order, takes the i-th and
 // re-minimises it without the batch's members; the finish kernel installs the results if the whole batch commits and
 // the preselection (a later workgroup of the same grid) waits for the ones it needs instead of scanning itself.
-__device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
+__device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                  int max_size, ward_state *__restrict__ st, float *sv, int *si)
 {
@@ -1121,7 +1121,7 @@ __device__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ 
     }
 }
 
-__device__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
+__device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                      const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int max_size,
                                      ward_state *__restrict__ st, float *sv, int *si, int *sh)
 {
@@ -1671,6 +1671,117 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
     }
 }
 
+// FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
+// (see ward_update_lw_kernel) instead of centroid recomputes -- 12 bytes of reads per live cluster and merge, so the
+// launch is as long as its preselection.  Same grid roles as ward_update_batch_kernel (spare re-minimisers, the
+// preselection, one "virtual slot" workgroup), then WB_THREADS slots per workgroup, one lane per cluster.  The distance
+// between two clusters created in the same batch nests the recurrence (D(c_i, a_j) is itself a Lance-Williams value of
+// stored entries), which is exactly what the one-merge-per-step loop would have stored and read back.
+__device__ __forceinline__ float ward_lw_value(float dax, float dbx, float dab, int sa, int sb, int sx)
+{
+    const float v = ((float)(sa + sx) * dax + (float)(sb + sx) * dbx - (float)sx * dab) / (float)(sa + sb + sx);
+    return v > 0.0f ? v : 0.0f; // keeps the (bits, column) key order == value order
+}
+
+__global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_t S, const int32_t *__restrict__ slot_id,
+                                                                         const int32_t *__restrict__ asz, const int64_t *__restrict__ rowoff,
+                                                                         float *__restrict__ Dtri, ward_state *__restrict__ st, int max_size, int64_t n,
+                                                                         float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int sh[8];
+    if (blockIdx.x < WB_R) {
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
+        return;
+    }
+    if (blockIdx.x == WB_R) {
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    if (done || nb <= 0) return;
+    int pa[WB_K], pb[WB_K], psa[WB_K], psb[WB_K];
+    float pv[WB_K];
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) {
+        pa[j] = st->B.a[j];
+        pb[j] = st->B.b[j];
+        psa[j] = st->B.sa[j];
+        psb[j] = st->B.sb[j];
+        pv[j] = st->B.val[j];
+    }
+    auto publish = [&](int j, unsigned long long key, unsigned long long key2) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+            const unsigned long long o2 = __shfl_down(key2, off, 64);
+            key2 = o2 < key2 ? o2 : key2;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
+        if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
+    };
+    if (blockIdx.x == WB_R + 1) {
+        // new-vs-new: thread (i, j), i < j < nb, gives D(c_j, c_i); one wave is enough (WB_K * WB_K <= 64)
+        static_assert(WB_K * WB_K <= 64, "one lane per (i, j)");
+        if (threadIdx.x >= 64) return;
+        const int vi = lane / WB_K, vj = lane % WB_K;
+#pragma unroll
+        for (int j = 1; j < WB_K; ++j) {
+            if (j >= nb) break;
+            unsigned long long key = ~0ull;
+            if (vj == j && vi < j) {
+                int ai = 0, bi = 0, sai = 0, sbi = 0;
+                float vi_val = 0.0f;
+#pragma unroll
+                for (int q = 0; q < WB_K; ++q)
+                    if (q == vi) {
+                        ai = pa[q];
+                        bi = pb[q];
+                        sai = psa[q];
+                        sbi = psb[q];
+                        vi_val = pv[q];
+                    }
+                const int sci = sai + sbi, scj = psa[j] + psb[j];
+                if (sci + scj <= max_size) {
+                    // D(c_i, a_j) and D(c_i, b_j) from stored entries, then D(c_j, c_i)
+                    const float d_ci_aj = ward_lw_value(tri_at(Dtri, rowoff, ai, pa[j]), tri_at(Dtri, rowoff, bi, pa[j]), vi_val, sai, sbi, psa[j]);
+                    const float d_ci_bj = ward_lw_value(tri_at(Dtri, rowoff, ai, pb[j]), tri_at(Dtri, rowoff, bi, pb[j]), vi_val, sai, sbi, psb[j]);
+                    const float v = ward_lw_value(d_ci_aj, d_ci_bj, pv[j], psa[j], psb[j], sci);
+                    const int ci = (int)(n + t + vi);
+                    Dtri[rowoff[n + t + j] + ci] = v;
+                    if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)ci;
+                }
+            }
+            publish(j, key, key); // a cluster created by this batch survives it
+        }
+        return;
+    }
+    const int64_t slot = ((int64_t)blockIdx.x - (WB_R + 2)) * WB_THREADS + threadIdx.x;
+    if (((int64_t)blockIdx.x - (WB_R + 2)) * WB_THREADS >= nlive) return;
+    const int x = slot < nlive && slot < S ? slot_id[slot] : -1;
+    const int sx = x >= 0 ? asz[x] : 0;
+    bool alive = x >= 0 && sx > 0;
+    bool survives = alive;
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j)
+        if (j < nb) survives = survives && x != pa[j] && x != pb[j];
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) {
+        if (j >= nb) break;
+        alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+        unsigned long long key = ~0ull;
+        if (alive && sx + psa[j] + psb[j] <= max_size) {
+            const float v = ward_lw_value(tri_at(Dtri, rowoff, pa[j], x), tri_at(Dtri, rowoff, pb[j], x), pv[j], psa[j], psb[j], sx);
+            Dtri[rowoff[n + t + j] + x] = v;
+            if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
+        }
+        publish(j, key, survives ? key : ~0ull);
+    }
+}
+
 // finish for a batch: (1) validate + commit the longest valid prefix of the tentative picks (bookkeeping of
 // MergeClusters / RemoveClusters, clustering.go:29-58,:240-241; centroid images into CT4 / Crow; slot compaction);
 // (2) choose the next batch from {rows just created} U {preselected old-row pairs}; (3) merged centroids (:37-40).
@@ -1708,8 +1819,9 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
                                                                 float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                                                 int32_t *__restrict__ merges, const float *__restrict__ Dtri,
-                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st)
+                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st, int lw)
 {
+    // lw != 0 (FAST mode): the rows come from the Lance-Williams recurrence, no centroid is kept: only the bookkeeping runs
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int sh[8];
@@ -1961,6 +2073,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     const int t = t0 + J;
     const bool fast = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // the preselection's assumption held
     WB_TIMER(if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;)
+    if (sh[2] && lw) return;
     if (sh[2]) {
         // one data phase, one k-group per thread: centroid images of the committed clusters (cnew_j into a's slot, THEN
         // the compaction move) and the merged centroids of the next batch (clustering.go:37-40), in chunks of 8
@@ -2041,7 +2154,9 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
         return;
     }
-    if (wave != 0 || t >= target || !fast) {
+    if (lw) {
+        // nothing to copy
+    } else if (wave != 0 || t >= target || !fast) {
         // centroid images of the committed clusters: cnew_j into a's slot, THEN the compaction move (which may move it)
         const int nthr = (t >= target || !fast) ? (int)blockDim.x : (int)blockDim.x - 64;
         const int tid = (t >= target || !fast) ? (int)threadIdx.x : (int)threadIdx.x - 64;
@@ -2354,7 +2469,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             st->B.pre_for_nb = -1;
         }
     }
-    {
+    if (!lw) {
         // MergeClusters centroid (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb) / float(sa+sb), each op rounded
         int sla[WB_K], slb[WB_K];
         float fa[WB_K], fb[WB_K], fs[WB_K];
@@ -2751,15 +2866,16 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const char *e = getenv("ICL_WARD_BATCH");
         return !(e && e[0] == '0');
     }();
-    const bool batched = !lw && batch_env;
+    const bool batched = batch_env; // both modes: exact centroid chains, or Lance-Williams rows (lw)
     ward_state hst;
     if (batched) {
         // Batched exact mode: each step attempts up to WB_K independent merges, so the number of steps is data
         // dependent (between T/WB_K and T).  Steps are enqueued in chunks of GRAPH_STEPS; the state is read back after
         // each chunk, one chunk behind the launches so the queue never drains.
         const int dqb = (int)wb_groups(d);
+        const unsigned lw_blocks_b = (unsigned)icl_ceil_div(w->S, WB_THREADS) + 2 + WB_R;
         const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * dqb * 16;
-        if (wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+        if (!lw && wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
         static bool wb_attr = false;
         if (!wb_attr) {
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); // + the preselection's static arrays
@@ -2768,9 +2884,14 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const unsigned wb_blocks = (unsigned)((w->S / 64 + 7) / 8 * 8) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
-                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st);
+                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0);
         };
         auto update_b = [&]() {
+            if (lw) {
+                hipLaunchKernelGGL(ward_update_batch_lw_kernel, dim3(lw_blocks_b), dim3(WB_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff,
+                                   w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+                return;
+            }
             hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow, w->cnew,
                                w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
         };
@@ -2786,7 +2907,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         };
         finish_b(); // first batch: one pick by the plain lazy selection
         const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != 2)) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2))) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -2797,7 +2918,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = 2;
+            w->graph_lw = lw ? 3 : 2;
         }
         ward_state *hpin = nullptr; // two pinned snapshots
         ICL_HIP(ctx, hipHostMalloc((void **)&hpin, 2 * sizeof(ward_state), hipHostMallocDefault));
@@ -2876,8 +2997,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ctx->ward_stats[2] = hst.B.slow;
         ctx->ward_stats[3] = (int64_t)hst.B.sum_live;
         if (prof_update) { // algorithmic work of the launches just profiled (n_live is only known on the device)
-            ctx->prof[ICL_K_UPDATE].flops += 3.0 * d * (double)hst.B.sum_live_nb;
-            ctx->prof[ICL_K_UPDATE].bytes += 4.0 * d * (double)hst.B.sum_live + 4.0 * (double)hst.B.sum_live_nb;
+            ctx->prof[ICL_K_UPDATE].flops += (lw ? 8.0 : 3.0 * d) * (double)hst.B.sum_live_nb;
+            ctx->prof[ICL_K_UPDATE].bytes += lw ? 12.0 * (double)hst.B.sum_live_nb : 4.0 * d * (double)hst.B.sum_live + 4.0 * (double)hst.B.sum_live_nb;
         }
     } else {
         ctx->ward_stats[1] = nmerge;
