@@ -129,6 +129,7 @@ def main():
     E_local = torch.empty((max(n_local, 1), DIM), dtype=torch.float32, device=dev)[:n_local]
     update = _lib.UPDATE_LW if args.update == "lw" else _lib.UPDATE_EXACT
     result = {}
+    keep = {}
 
     def step():
         ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), DIM, _lib.PREC_BF16)  # returns with the stream idle
@@ -146,6 +147,7 @@ def main():
         if args.embed_only:
             return
         if rank == 0:
+            keep["E_full"] = E_full  # rank 0 re-uses the gathered matrix for the untimed profiling pass (no second collective)
             cid, mrank, nc = ctx.cluster_dev(E_full.data_ptr(), n_total, DIM, args.min_size, args.max_size, update)
             st = ctx.last_stage_ms()
             result.update(dist_ms=st["dist_ms"], merge_ms=st["merge_ms"], n_clusters=nc, merges=len(ctx.last_merges()),
@@ -188,9 +190,8 @@ def main():
         # The timed steps replay the merge loop from a hipGraph, where single launches cannot be bracketed with events.
         # One extra, UNTIMED clustering pass over the same E runs the identical kernels eagerly with a HIP event pair around
         # every ward_update_exact_kernel launch (on the engine's stream) to get that kernel's average duration.
-        E_prof = D.gather_embeddings(E_local, n_total, rank, world) if (world > 1 and args.dist_backend == "nccl") else None
-        if world == 1:
-            E_prof = E_local
+        # NOTE: only rank 0 runs this block, so it must not call a collective: it re-uses the matrix gathered in the last step
+        E_prof = keep.get("E_full")
         if E_prof is not None:
             ctx.prof_reset()
             ctx.prof_enable(1 << _lib.K_UPDATE)
