@@ -64,6 +64,30 @@ def cpu_baseline(n_embed=16, n_ward=1500, d=2048):
             "embed_images_per_sec": round(embed_rate, 3), "ward_seconds": round(t_ward, 3), "ward_n": n_ward}
 
 
+def layerwise_roofline_seconds(batch):
+    """Sum over the ResNet50-v1 launches of max(flops / bf16 MFMA peak, HBM bytes / HBM peak) for one batch: the time the
+    forward pass would take if every layer sat on its own roofline (activations bf16 NHWC, each tensor read and written
+    once per launch, residual read once, downsample branch fused).  Context for the per-kernel roofline fraction: most
+    1x1 layers are HBM-side, the 3x3 layers MFMA-side."""
+    B = batch
+    lay = [(2 * B * 112 * 112 * 64 * 147, B * 224 * 224 * 3 + B * 112 * 112 * 64 * 2), (0, B * 112 * 112 * 64 * 2 + B * 56 * 56 * 64 * 2)]
+    h, cin = 56, 64
+    for s, nb in enumerate([3, 4, 6, 3]):
+        cout = 256 << s
+        mid = cout // 4
+        for bl in range(nb):
+            ho = h // (2 if (bl == 0 and s > 0) else 1)
+            lay.append((2 * B * ho * ho * mid * cin, (B * h * h * cin + B * ho * ho * mid) * 2))
+            lay.append((2 * B * ho * ho * mid * mid * 9, B * ho * ho * mid * 2 * 2))
+            if bl == 0:
+                lay.append((2 * B * ho * ho * cout * (mid + cin), (B * ho * ho * mid + B * h * h * cin + B * ho * ho * cout) * 2))
+            else:
+                lay.append((2 * B * ho * ho * cout * mid, (B * ho * ho * mid + 2 * B * ho * ho * cout) * 2))
+            cin, h = cout, ho
+    lay.append((0, B * 49 * 2048 * 2))
+    return sum(max(f / (PEAK_BF16_TFLOPS * 1e12), b / (PEAK_HBM_GBS * 1e9)) for f, b in lay)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +246,8 @@ def main():
                      "algorithmic_flops_per_launch": round(c128["flops"] / max(c128["launches"], 1), 0),
                      "all_conv_achieved": round((c128["flops"] + c64["flops"]) / max(c128["ms"] + c64["ms"], 1e-9) / 1e9, 2),
                      "embed_frac_of_bf16_peak": round(n_local * FLOP_PER_IMAGE / max(result.get("embed_ms", 0), 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                     "embed_frac_of_layerwise_roofline": round(layerwise_roofline_seconds(args.batch) * 1e3 * n_local / args.batch
+                                                               / max(result.get("embed_ms", 0), 1e-9), 4),
                      "measured": "HIP events around every launch in one extra untimed single-stream pass over the same images (the timed steps keep two forward passes in flight on two streams)"}
         # dominant kernel by total GPU time (rocprofv3 stats in profiles/): the 128x128 implicit-GEMM conv (MFMA bound);
         # the Ward update kernel (HBM bound: one pass over the live centroids per launch) is reported beside it
