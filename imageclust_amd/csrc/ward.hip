@@ -30,7 +30,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_TIMER(stmt)
 #endif
 #ifndef WB_K
-#define WB_K 8 /* merges attempted per batched step (16 was measured: same total, the preselection and the finish kernel grow as fast as the update shrinks) */
+#define WB_K 8 /* merges attempted per batched step; must be a power of two <= 16 (16 was measured twice: same total, the preselection and the finish kernel grow as fast as the update shrinks) */
+static_assert((WB_K & (WB_K - 1)) == 0 && WB_K >= 4 && WB_K <= 16, "lane-indexed tables assume a power of two");
 #endif
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
 #define WB_RM 4 /* rows each of them takes (matches wg, wg + WB_R, ...): hub clusters leave hundreds of rows dirty */
@@ -1724,10 +1725,10 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
         if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
     };
     if (blockIdx.x == WB_R + 1) {
-        // new-vs-new: thread (i, j), i < j < nb, gives D(c_j, c_i); one wave is enough (WB_K * WB_K <= 64)
-        static_assert(WB_K * WB_K <= 64, "one lane per (i, j)");
-        if (threadIdx.x >= 64) return;
-        const int vi = lane / WB_K, vj = lane % WB_K;
+        // new-vs-new: thread (i, j), i < j < nb, gives D(c_j, c_i); whole waves take part in the key reduction
+        static_assert(WB_K * WB_K <= WB_THREADS, "one thread per (i, j)");
+        if ((int)(threadIdx.x & ~63u) >= WB_K * WB_K) return;
+        const int vi = (int)threadIdx.x / WB_K, vj = (int)threadIdx.x % WB_K; // vi >= WB_K: idle lane of the last wave
 #pragma unroll
         for (int j = 1; j < WB_K; ++j) {
             if (j >= nb) break;
