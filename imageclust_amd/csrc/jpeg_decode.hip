@@ -13,6 +13,7 @@
 #include "icl_common.h"
 
 #include <cstring>
+#include <new>
 #include <vector>
 
 namespace {
@@ -216,8 +217,23 @@ void idct_islow(const int *coef, uint8_t *out, int stride)
 
 } // namespace
 
-// Decodes a JPEG file held in memory to interleaved RGB.  rgb is resized to w*h*3.
+#define ICL_JPEG_MAX_PIXELS (64LL << 20)
+static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H);
+
+// Decodes a JPEG file held in memory to interleaved RGB.  rgb is resized to w*h*3.  No C++ exception may cross the C ABI
+// (cgo / ctypes would std::terminate the host process): allocation failures become status codes here.
 int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H)
+{
+    try {
+        return jpeg_decode_impl(ctx, data, len, path, rgb, W, H);
+    } catch (const std::bad_alloc &) {
+        return icl_fail(ctx, ICL_ERR_NOMEM, "failed to read image: %s. Out of host memory while decoding", path);
+    } catch (...) {
+        return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Decoder error", path);
+    }
+}
+
+static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H)
 {
     auto fail = [&](int code, const char *what) { return icl_fail(ctx, code, "failed to read image: %s. %s", path, what); };
     if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(ICL_ERR_IO, "Not a JPEG stream");
@@ -265,6 +281,13 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
                 for (int l = 1; l <= 16; ++l) { t.bits[l] = s[i + l]; total += t.bits[l]; }
                 i += 17;
                 if (total > 256 || i + total > sl) return fail(ICL_ERR_IO, "Bad Huffman table");
+                // the counts must form a prefix code (as IJG jdhuff.c checks): at every length the codes handed out so
+                // far fit in l bits -- otherwise build()'s lookahead index runs past fast[512] (over-subscribed table)
+                for (int l = 1, code = 0; l <= 16; ++l) {
+                    code += t.bits[l];
+                    if (code > (1 << l)) return fail(ICL_ERR_IO, "Bad Huffman table");
+                    code <<= 1;
+                }
                 memcpy(t.vals, s + i, (size_t)total);
                 i += total;
                 t.present = true;
@@ -279,6 +302,8 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
             ncomp = s[5];
             if ((ncomp != 1 && ncomp != 3) || sl < (size_t)(6 + 3 * ncomp) || W <= 0 || H <= 0 || W > 32768 || H > 32768)
                 return fail(ICL_ERR_UNSUPPORTED, "Only 1- or 3-component JPEG is decoded");
+            // sizes come from the file: bound what they make us allocate (coefficients + planes + RGB, ~11 B per pixel)
+            if ((int64_t)W * H > ICL_JPEG_MAX_PIXELS) return fail(ICL_ERR_UNSUPPORTED, "JPEG larger than 64 Mpixel is not decoded");
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = s[6 + 3 * c];
                 comp[c].h = s[7 + 3 * c] >> 4;
@@ -314,6 +339,7 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
             if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
         } else if (m == 0xDA) { // SOS: one scan (a baseline file has one or ncomp of them, a progressive file many)
             if (!have_sof) return fail(ICL_ERR_IO, "Scan before frame header");
+            if (sl < 1) return fail(ICL_ERR_IO, "Bad scan header");
             const int ns = s[0];
             if (ns < 1 || ns > ncomp || sl < (size_t)(1 + 2 * ns + 3)) return fail(ICL_ERR_IO, "Bad scan header");
             int sc[3];

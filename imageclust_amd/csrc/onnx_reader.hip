@@ -15,6 +15,7 @@
 
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -86,17 +87,23 @@ struct onnx_tensor {
     int dtype = 0;
     span raw, fdata; // raw_data bytes, or packed float_data
     std::vector<float> loose; // unpacked float_data entries (wire type 5), rare
-    int64_t count() const
+    int64_t count() const // -1: a dimension is negative or the product leaves the range a file of this size can hold
     {
         int64_t c = 1;
-        for (auto d : dims) c *= d;
+        for (auto d : dims) {
+            if (d < 0 || (d > 0 && c > ((int64_t)1 << 40) / d)) return -1;
+            c *= d;
+        }
         return c;
     }
     bool floats(std::vector<float> &out) const
     {
         const int64_t c = count();
+        // dims come from the file: the payload (raw_data, float_data or loose entries) must hold exactly c floats, so c
+        // is bounded by what was actually read before anything is allocated
+        if (dtype != 1 || c < 0) return false; // FLOAT
+        if (!(raw.n == (size_t)c * 4 || fdata.n == (size_t)c * 4 || (int64_t)loose.size() == c)) return false;
         out.resize((size_t)c);
-        if (dtype != 1) return false; // FLOAT
         if (raw.n == (size_t)c * 4) { memcpy(out.data(), raw.p, raw.n); return true; }
         if (fdata.n == (size_t)c * 4) { memcpy(out.data(), fdata.p, fdata.n); return true; }
         if ((int64_t)loose.size() == c) { out = loose; return true; }
@@ -207,8 +214,22 @@ static int resnet50_topology_onnx(icl_conv_rec *out)
 
 } // namespace
 
-// Parses an ONNX file into an ICLW blob.  Returns ICL_OK or ICL_ERR_IO with a message in ctx.
+static int onnx_to_blob_impl(icl_ctx *ctx, const char *path, std::vector<char> &blob);
+
+// Parses an ONNX file into an ICLW blob.  Returns ICL_OK or ICL_ERR_IO with a message in ctx.  No C++ exception may cross
+// the C ABI above this call: allocation failures on hostile sizes become status codes here.
 int icl_onnx_to_blob(icl_ctx *ctx, const char *path, std::vector<char> &blob)
+{
+    try {
+        return onnx_to_blob_impl(ctx, path, blob);
+    } catch (const std::bad_alloc &) {
+        return icl_fail(ctx, ICL_ERR_NOMEM, "failed to load ResNet50 ONNX model from: %s (out of host memory)", path);
+    } catch (...) {
+        return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s (malformed file)", path);
+    }
+}
+
+static int onnx_to_blob_impl(icl_ctx *ctx, const char *path, std::vector<char> &blob)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) return icl_fail(ctx, ICL_ERR_IO, "failed to load ResNet50 ONNX model from: %s", path); // embeddings.go:32

@@ -2794,10 +2794,19 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (n == 0) return ICL_OK;
     ICL_TRY(ward_ensure(ctx, n, d));
     icl_ward_ws *w = ctx->ward;
-    hipEvent_t e0, e1, e2;
-    ICL_HIP(ctx, hipEventCreate(&e0));
-    ICL_HIP(ctx, hipEventCreate(&e1));
-    ICL_HIP(ctx, hipEventCreate(&e2));
+    // every early return below (ICL_HIP / ICL_TRY / icl_fail) releases these through the guards' destructors
+    struct ev_guard {
+        hipEvent_t e = nullptr;
+        ~ev_guard() { if (e) (void)hipEventDestroy(e); }
+    } g0, g1, g2, gv0, gv1;
+    struct pin_guard {
+        void *p = nullptr;
+        ~pin_guard() { if (p) (void)hipHostFree(p); }
+    } gpin;
+    ICL_HIP(ctx, hipEventCreate(&g0.e));
+    ICL_HIP(ctx, hipEventCreate(&g1.e));
+    ICL_HIP(ctx, hipEventCreate(&g2.e));
+    hipEvent_t &e0 = g0.e, &e1 = g1.e, &e2 = g2.e;
     ICL_HIP(ctx, hipEventRecord(e0, ctx->stream));
 
     {
@@ -2921,11 +2930,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             w->graph_max_size = max_size;
             w->graph_lw = lw ? 3 : 2;
         }
-        ward_state *hpin = nullptr; // two pinned snapshots
-        ICL_HIP(ctx, hipHostMalloc((void **)&hpin, 2 * sizeof(ward_state), hipHostMallocDefault));
-        hipEvent_t evs[2];
-        ICL_HIP(ctx, hipEventCreateWithFlags(&evs[0], hipEventDisableTiming));
-        ICL_HIP(ctx, hipEventCreateWithFlags(&evs[1], hipEventDisableTiming));
+        ICL_HIP(ctx, hipHostMalloc(&gpin.p, 2 * sizeof(ward_state), hipHostMallocDefault));
+        ward_state *hpin = (ward_state *)gpin.p; // two pinned snapshots
+        ICL_HIP(ctx, hipEventCreateWithFlags(&gv0.e, hipEventDisableTiming));
+        ICL_HIP(ctx, hipEventCreateWithFlags(&gv1.e, hipEventDisableTiming));
+        hipEvent_t evs[2] = {gv0.e, gv1.e};
         auto finished = [&](const ward_state &h) { return h.done || h.t >= T; };
         int rc_b = ICL_OK;
         int64_t chunk = 0;
@@ -2947,9 +2956,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             ++chunk;
         }
         if (rc_b == ICL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc_b = ICL_ERR_HIP;
-        (void)hipEventDestroy(evs[0]);
-        (void)hipEventDestroy(evs[1]);
-        (void)hipHostFree(hpin);
         if (rc_b != ICL_OK) return icl_fail(ctx, ICL_ERR_HIP, "batched merge loop: %s", hipGetErrorString(hipGetLastError()));
     } else {
     hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff,
@@ -2979,6 +2985,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 
     ICL_HIP(ctx, hipMemcpyAsync(&hst, w->st, sizeof hst, hipMemcpyDeviceToHost, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // The loop ends when len(clusters) == k or no mergeable pair is left (clustering.go:220-225).  Anything else -- the chunk
+    // budget of the batched loop ran out, a replay did nothing -- is an engine failure, never a shorter clustering.
+    if (!(hst.done || hst.t >= T))
+        return icl_fail(ctx, ICL_ERR_HIP, "merge loop did not converge: %d of %lld merges after the step budget (engine bug, not a property of the input)",
+                        hst.t, (long long)T);
     const int64_t nmerge = hst.t;
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
@@ -3022,9 +3033,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     (void)hipEventElapsedTime(&ms12, e1, e2);
     ctx->last_dist_ms = ms01;
     ctx->last_merge_ms = ms12;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
     icl_prof_collect(ctx);
     int rc = assign_ids(ctx, n, min_size, max_size, pairs, nmerge, cluster_id, member_rank, n_clusters);
     ctx->last_merges.swap(pairs);

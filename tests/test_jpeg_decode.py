@@ -114,3 +114,70 @@ def test_load_image_224_identity_and_resize(tmp_path):
     const = np.full((50, 70, 3), 77, np.uint8)
     (tmp_path / "c.ppm").write_bytes(b"P6\n70 50\n255\n" + const.tobytes())
     assert (_lib.load_image_224(str(tmp_path / "c.ppm")) == 77).all()
+
+
+# ---- hostile files (the decoder runs on uploaded / downloaded product images: embeddings.go:50) ----
+def _jpeg_bytes(h=16, w=16, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(picture(h, w, 3)).save(buf, "JPEG", **kw)
+    return bytearray(buf.getvalue())
+
+
+def _find_marker(b, m):
+    i = 2
+    while i + 4 <= len(b):
+        assert b[i] == 0xFF
+        if b[i + 1] == m:
+            return i
+        i += 2 + ((b[i + 2] << 8) | b[i + 3])
+    raise AssertionError("marker %02x not found" % m)
+
+
+@pytest.mark.parametrize("bits1", [3, 255])
+def test_oversubscribed_huffman_table_is_rejected(tmp_path, bits1):
+    """A DHT whose code-length counts are no prefix code (3 or 255 one-bit codes) must be refused, not indexed with."""
+    b = _jpeg_bytes(quality=80)
+    i = _find_marker(b, 0xC4)
+    b[i + 5] = bits1  # bits[1] of the first table in the segment
+    p = tmp_path / "bad_dht.jpg"
+    p.write_bytes(bytes(b))
+    with pytest.raises(_lib.ICLError, match="Bad Huffman table"):
+        _lib.decode_image_file(str(p))
+
+
+def test_truncated_scan_header_is_rejected(tmp_path):
+    b = _jpeg_bytes(quality=80)
+    i = _find_marker(b, 0xDA)
+    cut = bytes(b[:i]) + b"\xff\xda\x00\x02"  # SOS with seglen == 2 as the last bytes of the file
+    p = tmp_path / "cut_sos.jpg"
+    p.write_bytes(cut)
+    with pytest.raises(_lib.ICLError):
+        _lib.decode_image_file(str(p))
+
+
+def test_huge_frame_header_is_refused_without_allocating(tmp_path):
+    b = _jpeg_bytes(quality=80)
+    i = _find_marker(b, 0xC0)
+    b[i + 5 : i + 9] = bytes([0x80, 0x00, 0x80, 0x00])  # H = W = 32768 in a 1 KB file: ~11 GB of buffers if believed
+    p = tmp_path / "huge.jpg"
+    p.write_bytes(bytes(b))
+    with pytest.raises(_lib.ICLError, match="64 Mpixel"):
+        _lib.decode_image_file(str(p))
+
+
+def test_mutated_files_never_crash(tmp_path):
+    """Byte-flip fuzz over headers and entropy data: every outcome is a decoded image or an ICLError."""
+    rng = np.random.default_rng(7)
+    base = [_jpeg_bytes(24, 40, quality=70), _jpeg_bytes(33, 17, quality=90, progressive=True, subsampling=2)]
+    p = tmp_path / "m.jpg"
+    for it in range(300):
+        b = bytearray(base[it & 1])
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+        if it % 7 == 0:
+            b = b[: int(rng.integers(4, len(b)))]
+        p.write_bytes(bytes(b))
+        try:
+            _lib.decode_image_file(str(p))
+        except _lib.ICLError:
+            pass
