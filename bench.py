@@ -5,11 +5,11 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
     u8 images (per rank) -> ResNet50-v1 bf16 embed (batch 256) -> [N>1: RCCL all-gather of E over xGMI]
     -> size-constrained Ward (min=5, max=50, exact update: cluster ids bit-identical to the reference)
     -> cluster_id[N] on the host.
-N=1 runs BASELINE.json configs[1] (10 000 synthetic 224x224x3 images, 1 GPU).  N>1 defaults to STRONG scaling of the
-same 10 000-image job ("images/sec ... at 1/2/4/8 MI355X" of one dataset): the images are sharded over the ranks for the
-embed, E is all-gathered, rank 0 clusters it (configs[2]'s shape: "Ward on GPU0").  The Ward merge loop is sequential
-and stays on one GPU, so the speed-up is Amdahl-limited by it; `--scaling weak` keeps 10 000 images PER GPU instead
-(the clustered set then grows with N and Ward's O(N^2 D) work dominates).
+The workload is the one BASELINE.json's metric is quoted on: "images/sec (embed+Ward) on 100k 224x224 imgs at 1/2/4/8
+MI355X" -- 100 000 synthetic images (configs[2]'s N; it fits one 288 GB GPU: 15 GB of images, 80 GB distance triangle).
+N=1 runs the whole job on one GPU; N>1 STRONG-scales the same 100 000-image job: the images are sharded over the ranks
+for the embed, E is all-gathered, rank 0 clusters it (configs[2]'s shape: "Ward on GPU0").  `--total-images 10000` is
+configs[1] (its line is quoted in README.md); `--scaling weak` keeps --images-per-gpu images PER GPU instead.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -34,34 +34,57 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 3857973248  # 53 conv + 1 fc, MACs x 2
 
 
-def cpu_baseline(n_embed=16, n_ward=1500, d=2048):
-    """The CPU restatement of the reference algorithm (oracle/, kind "port"), timed on this box's host cores."""
+def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s=75.0):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port"), timed on this box's host cores as SURVEY.md
+    8d prescribes: (i) embed = the fp32 ResNet50 restatement, batch 1, serial calls, all cores inside a call (OpenCV-DNN is
+    internally multi-threaded, embeddings.go:133-141), 64 images; (ii) Ward = the literal O(N^3) restatement, ONE thread
+    (the reference clusters on one goroutine, workflow.go:89), at N in {64, 1000, 2000, 4000}, D=2048, (min,max) = (3,6)
+    for N=64 (handlers.go:111) and (5,50) otherwise, with the fitted a*N^3 + b*N^2*D model.  Nothing is extrapolated to
+    100k: `value` is the measured rate of the largest measured job (embed N images + cluster them)."""
     from oracle import oracle as O
     from imageclust_amd import _lib
 
     # the oracle's OpenMP team: the CPUs this process may run on, capped at 16 (a 1-GPU box's CPU share)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    t_start = time.perf_counter()
     blob = _lib.synthetic_blob(1)
     imgs = _lib.synth_images(20250217, 0, n_embed, _lib.SYNTH_STRUCTURED)
     O.resnet50_forward(blob, imgs[0])  # warm
     t0 = time.perf_counter()
+    done = 0
     for im in imgs:
         O.resnet50_forward(blob, im)  # batch 1, serial calls, OpenMP inside: as embeddings.go:133-141
+        done += 1
+        if time.perf_counter() - t0 > 0.55 * budget_s:
+            break
     t_embed = time.perf_counter() - t0
+    embed_rate = done / t_embed
     rng = np.random.default_rng(20250217)
-    cen = rng.standard_normal((n_ward // 20, d)).astype(np.float32)
-    E = (cen[rng.integers(0, len(cen), n_ward)] + 0.1 * rng.standard_normal((n_ward, d))).astype(np.float32)
-    t0 = time.perf_counter()
-    O.cluster(E, 5, 50)
-    t_ward = time.perf_counter() - t0
-    embed_rate = n_embed / t_embed
-    value = n_ward / (n_ward / embed_rate + t_ward)
+    ward = []
+    for n_ward in ward_sizes:
+        if ward and time.perf_counter() - t_start + ward[-1][1] * (n_ward / ward[-1][0]) ** 3 > budget_s:
+            break  # the next size would not fit the budget on this host: report what was measured
+        cen = rng.standard_normal((max(n_ward // 20, 1), d)).astype(np.float32)
+        E = (cen[rng.integers(0, len(cen), n_ward)] + 0.1 * rng.standard_normal((n_ward, d))).astype(np.float32)
+        mn, mx = (3, 6) if n_ward == 64 else (5, 50)
+        t0 = time.perf_counter()
+        O.cluster(E, mn, mx, threads=1)
+        ward.append((n_ward, time.perf_counter() - t0))
+    # least squares for t = a*N^3 + b*N^2*D (the scan and the distance/row-refresh terms of SURVEY.md 3.3)
+    A = np.array([[float(n) ** 3, float(n) ** 2 * d] for n, _ in ward])
+    coef, *_ = np.linalg.lstsq(A, np.array([t for _, t in ward]), rcond=None)
+    n_big, t_big = ward[-1]
+    value = n_big / (n_big / embed_rate + t_big)
     return {"value": round(value, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle/ CPU restatement: embed %d images (batch 1, OpenMP %d threads, %.2f img/s) + Ward N=%d D=%d "
-                      "min=5 max=50 (1 thread, %.2f s); value = %d/(%d/embed_rate + t_ward)"
-                      % (n_embed, cores, embed_rate, n_ward, d, t_ward, n_ward, n_ward),
-            "embed_images_per_sec": round(embed_rate, 3), "ward_seconds": round(t_ward, 3), "ward_n": n_ward}
+            "sample": "oracle/ CPU restatement: embed %d images (batch 1, serial calls, OpenMP %d threads: %.2f img/s) + Ward D=%d on 1 "
+                      "thread at N=%s (%s s); value = the measured N=%d job: %d/(%d/embed_rate + %.2f s); no size beyond "
+                      "N=%d is measured or extrapolated" % (done, cores, embed_rate, d, [n for n, _ in ward],
+                                                           ", ".join("%.2f" % t for _, t in ward), n_big, n_big, n_big, t_big, n_big),
+            "embed_images_per_sec": round(embed_rate, 3), "embed_images": done,
+            "ward_seconds": {str(n): round(t, 3) for n, t in ward},
+            "ward_fit": {"model": "t = a*N^3 + b*N^2*D seconds", "a": float("%.4g" % coef[0]), "b": float("%.4g" % coef[1])},
+            "seconds_total": round(time.perf_counter() - t_start, 1)}
 
 
 def layerwise_roofline_seconds(batch):
@@ -93,7 +116,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--total-images", type=int, default=10000, help="strong scaling: images of the whole job")
+    ap.add_argument("--total-images", type=int, default=100000, help="strong scaling: images of the whole job (100000 = the metric's size, 10000 = configs[1])")
     ap.add_argument("--images-per-gpu", type=int, default=10000, help="weak scaling: images per rank")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -232,14 +255,18 @@ def main():
         # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
         # two separate rocprofv3 --pmc passes of `bench.py --embed-only`); committed under profiles/ because bench.py
         # itself cannot run under the profiler.
-        traffic = traffic_upd = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v2.json")) as f:
-                pmc = json.load(f)
-            traffic = round(pmc["conv_igemm_kernel<BF16,128>"]["hbm_bytes_per_launch"], 0)
-            traffic_upd = round(pmc["ward_update_batch_kernel"]["hbm_bytes_per_launch"], 0)
-        except Exception:
-            pass
+        traffic = traffic_upd = pmc_file = None
+        for pmc_file in ("r02_pmc_traffic.json", "r01_pmc_traffic_v2.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                    pmc = json.load(f)
+                traffic = round(pmc["conv_igemm_kernel<BF16,128>"]["hbm_bytes_per_launch"], 0)
+                traffic_upd = round(pmc["ward_update_batch_kernel"]["hbm_bytes_per_launch"], 0)
+                traffic_note = pmc.get("note_ward", "")
+                break
+            except Exception:
+                traffic_note = ""
+                continue
         conv_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                      "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
@@ -249,9 +276,6 @@ def main():
                      "embed_frac_of_layerwise_roofline": round(layerwise_roofline_seconds(args.batch) * 1e3 * n_local / args.batch
                                                                / max(result.get("embed_ms", 0), 1e-9), 4),
                      "measured": "HIP events around every launch in one extra untimed single-stream pass over the same images (the timed steps keep two forward passes in flight on two streams)"}
-        # dominant kernel by total GPU time (rocprofv3 stats in profiles/): the 128x128 implicit-GEMM conv (MFMA bound);
-        # the Ward update kernel (HBM bound: one pass over the live centroids per launch) is reported beside it
-        roof = conv_roof
         ward_roof = None
         if upd and upd["launches"]:
             ws = ctx.last_ward_stats()
@@ -260,8 +284,7 @@ def main():
             ward_roof = {"bound": "hbm", "kernel": "ward_update_batch_kernel" if exact else "ward_update_lw_kernel",
                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
-                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE over the first 40 launches (n_live ~ 9850: 81 MB algorithmic), "
-                                         "profiles/r01_pmc_traffic_v2.json",
+                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note),
                          "launches": upd["launches"],
                          "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
                          "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),
@@ -269,25 +292,34 @@ def main():
                          "algorithmic_unit": "4*n_live*D bytes (one pass over the live centroids) + 4*n_live per new row, per LAUNCH; a launch "
                                              "computes the rows of up to 8 independent merges from that one pass (SURVEY.md 8d quotes "
                                              "4*n_live*D per merge)",
-                         "note": "bound by the D dependent fp32 adds of each in-order sum (one wave per merge row and 64 clusters), "
-                                 "not by HBM; launches after the last merge of a 64-step chunk are empty",
+                         "note": "at n_live >~ 30 000 one pass over the live centroids per launch is HBM-bound; below that the D "
+                                 "dependent fp32 adds of each in-order sum (one wave per merge row and 64 clusters) bound it; launches "
+                                 "after the last merge of a 64-step chunk are empty",
+                         "total_ms_in_profile_pass": round(upd["ms"], 1),
                          "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
                                      "(the timed steps replay a hipGraph)"}
+        conv_roof["total_ms_in_profile_pass"] = round(c128["ms"], 1)
+        # `roofline` = the dominant kernel of THIS workload by GPU time in the profiling passes (at N=100 000 the batched Ward
+        # update, HBM bound; at configs[1]'s N=10 000 the 128x128 implicit-GEMM conv, MFMA bound); the other one sits beside it
+        ward_dominates = ward_roof is not None and upd["ms"] > c128["ms"]
+        roof = ward_roof if ward_dominates else conv_roof
         out = {
             "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 bf16 "
+            "config": {"workload": "%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 bf16 "
                                    "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d on GPU0 -> cluster ids on host"
-                                   % (n_total, n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
+                                   % ("the metric's size (configs[2]'s N=100000) on %d GPU%s" % (world, "s" if world > 1 else "") if n_total == 100000
+                                      else "configs[1]" if n_total == 10000 and world == 1 else "custom size",
+                                      n_total, n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
                        "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
                        "ward_update": "exact (ids bit-identical to the reference)" if args.update == "exact"
                        else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
             "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
             "roofline": roof,
-            "roofline_ward_update": ward_roof,
+            ("roofline_conv" if ward_dominates else "roofline_ward_update"): (conv_roof if ward_dominates else ward_roof),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -2916,7 +2916,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             finish_b();
         };
         finish_b(); // first batch: one pick by the plain lazy selection
-        const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
+        static const bool graph_env = [] { // ICL_WARD_GRAPH=0: eager launches (diagnostic switch: profilers that cannot follow a graph replay)
+            const char *e = getenv("ICL_WARD_GRAPH");
+            return !(e && e[0] == '0');
+        }();
+        const bool use_graph = graph_env && !prof_update && T >= 2 * GRAPH_STEPS;
         if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2))) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;

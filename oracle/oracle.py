@@ -28,7 +28,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    srcs = [os.path.join(_HERE, f) for f in ("ward_ref.c", "resnet_ref.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("ward_ref.c", "ward_fast.c", "resnet_ref.c")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s)):
         build()
     L = C.CDLL(_SO)
@@ -47,6 +47,9 @@ def lib():
     L.icl_ref_cluster.restype = C.c_int
     L.icl_ref_cluster.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32p, i32p,
                                   C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.icl_fast_cluster.restype = C.c_int
+    L.icl_fast_cluster.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, i32p, i32p, C.POINTER(C.c_int32),
+                                   C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.icl_ref_resnet50_topology.restype = C.c_int
     L.icl_ref_resnet50_topology.argtypes = [C.c_void_p]
     L.icl_ref_resnet50_forward.restype = C.c_int
@@ -110,8 +113,9 @@ def calc_optimal_clusters(total, min_size, max_size):
     return (int(k.value), None) if rc == 0 else (0, rc)
 
 
-def cluster(E, min_size, max_size, want_log=False):
-    """Returns dict(ok, cluster_id, member_rank, n_clusters, merges, skips, log)."""
+def cluster(E, min_size, max_size, want_log=False, threads=None):
+    """Returns dict(ok, cluster_id, member_rank, n_clusters, merges, skips, log).  ward_ref.c is single-threaded by
+    construction (no OpenMP pragma: the reference clusters on one goroutine); `threads` is accepted for symmetry."""
     E = np.ascontiguousarray(E, np.float32)
     n, d = E.shape
     cid = np.full(max(n, 1), -1, np.int32)
@@ -123,6 +127,23 @@ def cluster(E, min_size, max_size, want_log=False):
                                C.byref(nc), log.ctypes.data if want_log else None, C.byref(nm), C.byref(ns))
     return dict(ok=(rc == 0), rc=rc, cluster_id=cid[:n], member_rank=rank[:n], n_clusters=int(nc.value),
                 merges=int(nm.value), skips=int(ns.value), log=(log[: nm.value] if want_log else None))
+
+
+def cluster_fast(E, min_size, max_size, lazy_ban=True, want_log=True):
+    """ward_fast.c: the sub-cubic restatement (O(n*D) per merge) for sizes ward_ref.c cannot reach.  Same outputs as
+    cluster() plus vals (the Ward value of every merged pair).  log rows: pos_i, pos_j, creation_id_i, creation_id_j."""
+    E = np.ascontiguousarray(E, np.float32)
+    n, d = E.shape
+    cid = np.full(max(n, 1), -1, np.int32)
+    rank = np.full(max(n, 1), -1, np.int32)
+    nc = C.c_int32()
+    nm, ns = C.c_int64(), C.c_int64()
+    log = np.zeros((max(n, 1), 4), np.int64) if want_log else None
+    vals = np.zeros(max(n, 1), np.float32)
+    rc = lib().icl_fast_cluster(E if n else np.zeros((1, max(d, 1)), np.float32), n, d, min_size, max_size, 1 if lazy_ban else 0,
+                                cid, rank, C.byref(nc), log.ctypes.data if want_log else None, vals.ctypes.data, C.byref(nm), C.byref(ns))
+    return dict(ok=(rc == 0), rc=rc, cluster_id=cid[:n], member_rank=rank[:n], n_clusters=int(nc.value), merges=int(nm.value),
+                skips=int(ns.value), log=(log[: nm.value] if want_log else None), vals=vals[: nm.value])
 
 
 def clusters_as_map(cluster_id, member_rank, ids):

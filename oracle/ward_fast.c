@@ -1,0 +1,245 @@
+/*
+ * oracle/ward_fast.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A second CPU restatement of /root/reference/internal/clustering/clustering.go
+ * (PerformClusteringWithConstraints :198-284) that reaches the sizes the literal
+ * O(N^3) restatement (ward_ref.c) cannot: O(n*D) arithmetic + O(n) bookkeeping per
+ * loop iteration, so N = 45 000 (D = 8) checks the HIP engine in seconds.
+ *
+ * It is NOT a copy of the HIP engine's data structures (no packed creation-id
+ * triangle, no batching, no lazy caches): clusters live in reusable SLOTS, every
+ * distance is stored once, in the row of the cluster that was created later, and
+ * every row keeps its exact (min, argmin).  What it shares with the engine is only
+ * the two facts about the reference that make any sub-cubic restatement possible:
+ *   - compacted positions are order-isomorphic to creation ids (RemoveClusters keeps
+ *     survivor order, :55-56; the merged cluster is appended last, :241), so the
+ *     row-major strict-'<' scan of FindClosestClusters (:123-131) returns the
+ *     lexicographic minimum of (value, larger creation id, smaller creation id);
+ *   - a new cluster is last, so all of its pairs sit in its own lower-triangle row.
+ * Arithmetic is the reference's, through the same helpers as ward_ref.c
+ * (icl_ref_ward_distance :136-157, icl_ref_merge_centroid :37-40), fp32 unfused.
+ *
+ * The MaxFloat32 ban (:228-234) is restated LITERALLY when lazy_ban != 0: the pair
+ * is found as the global minimum, then overwritten with MaxFloat32, then the loop
+ * continues (one "skip" iteration each, counted like ward_ref.c).  lazy_ban == 0
+ * applies the equivalent static mask (size_i + size_j > maxSize, sizes of live
+ * clusters never change) so that heavily constrained large inputs finish quickly;
+ * tests assert both modes equal each other and equal ward_ref.c.
+ *
+ * Parity status: pinned by bit-equality with ward_ref.c (ids, member ranks, merge log with positions, skip
+ * count) on every small case of the test suite; ward_ref.c itself is pinned by the
+ * hand-derived KATs of SURVEY.md 8c only -> "parity pinned by hand-derived KATs only".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ */
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FAST_MAXF FLT_MAX /* math.MaxFloat32, clustering.go:120,230 */
+
+float icl_ref_ward_distance(const float *ca, int64_t sa, const float *cb, int64_t sb, int64_t d); /* ward_ref.c */
+void icl_ref_merge_centroid(const float *ca, int64_t sa, const float *cb, int64_t sb, int64_t d, float *out);
+int icl_ref_calc_optimal_clusters(int64_t total, int64_t min_size, int64_t max_size, int64_t *k);
+
+typedef struct {
+    int64_t n, d, max_size;
+    int lazy_ban;
+    float *Dm;      /* [n][n] by slot: Dm[s][t] = Ward(s,t) is valid iff both alive and cid[t] < cid[s] */
+    float *cen;     /* [n][d] centroid of the cluster in each slot */
+    int64_t *cid;   /* creation id of the cluster in a slot */
+    int64_t *size;  /* its size, 0 = slot free */
+    float *rmin;    /* exact minimum of the slot's row (FAST_MAXF: nothing below MaxFloat32) */
+    int64_t *rarg;  /* slot of the row's first minimum in scan order (smallest creation id), -1 */
+    int64_t *live;  /* the nlive occupied slots, in no particular order (ties are decided by creation id, never by slot) */
+    int64_t nlive;
+} fast_state;
+
+/* Row scan in the reference's order: columns by increasing position == increasing creation id, strict '<'
+ * (clustering.go:124-130), so among equal values the smallest creation id wins. */
+static void rescan_row(fast_state *S, int64_t s)
+{
+    const float *row = S->Dm + s * S->n;
+    float best = FAST_MAXF;
+    int64_t arg = -1;
+    const int64_t me = S->cid[s];
+    for (int64_t q = 0; q < S->nlive; ++q) {
+        const int64_t t = S->live[q];
+        if (S->cid[t] >= me) continue;
+        float v = row[t];
+        if (!S->lazy_ban && S->size[s] + S->size[t] > S->max_size) v = FAST_MAXF; /* static form of :228-234 */
+        if (v < best || (v == best && arg >= 0 && S->cid[t] < S->cid[arg])) {
+            best = v;
+            arg = t;
+        }
+    }
+    S->rmin[s] = best;
+    S->rarg[s] = arg;
+}
+
+/*
+ * Outputs as icl_ref_cluster (cluster_id / member_rank / n_clusters), plus
+ *   merge_log   optional, 4 int64 per merge: pos_i, pos_j, creation_id_i, creation_id_j (i = higher position)
+ *   merge_vals  optional, the Ward value of each merged pair (the minimum FindClosestClusters returned)
+ * Returns 0, or 1/2/3 for the constraint errors, 4 if an oversize cluster is observed.
+ */
+int icl_fast_cluster(const float *E, int64_t n, int64_t d, int64_t min_size, int64_t max_size, int lazy_ban,
+                     int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters, int64_t *merge_log,
+                     float *merge_vals, int64_t *n_merges, int64_t *n_skips)
+{
+    int64_t k = 0;
+    int rc = icl_ref_calc_optimal_clusters(n, min_size, max_size, &k); /* :203 */
+    if (rc) return rc;
+    const int64_t nn = n > 0 ? n : 1;
+    fast_state S;
+    S.n = n;
+    S.d = d;
+    S.max_size = max_size;
+    S.lazy_ban = lazy_ban;
+    S.Dm = (float *)malloc((size_t)nn * nn * sizeof(float));
+    S.cen = (float *)malloc((size_t)nn * (d > 0 ? d : 1) * sizeof(float));
+    S.cid = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    S.size = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    S.rmin = (float *)malloc((size_t)nn * sizeof(float));
+    S.rarg = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    S.live = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    S.nlive = n;
+    /* member lists as singly linked chains over image indices: Merge(a,b) = a's members then b's (:31) */
+    int64_t *next = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    int64_t *head = (int64_t *)malloc((size_t)nn * sizeof(int64_t)); /* per slot */
+    int64_t *tail = (int64_t *)malloc((size_t)nn * sizeof(int64_t));
+    int64_t *redo = (int64_t *)malloc((size_t)nn * sizeof(int64_t)); /* rows to re-minimise after a merge */
+    if (!S.Dm || !S.cen || !S.cid || !S.size || !S.rmin || !S.rarg || !S.live || !next || !head || !tail || !redo) return 5;
+
+    memcpy(S.cen, E, (size_t)n * d * sizeof(float)); /* :211-214 NewCluster copies the embedding */
+    for (int64_t i = 0; i < n; ++i) {
+        S.cid[i] = i;
+        S.size[i] = 1;
+        S.live[i] = i;
+        next[i] = -1;
+        head[i] = tail[i] = i;
+    }
+    /* :217 ComputeInitialDistanceMatrix: row i holds its pairs with every j < i */
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i) {
+        float *row = S.Dm + i * n;
+        for (int64_t j = 0; j < i; ++j) row[j] = icl_ref_ward_distance(S.cen + i * d, 1, S.cen + j * d, 1, d);
+        rescan_row(&S, i);
+    }
+
+    int64_t len = n, merges = 0, skips = 0, next_cid = n;
+    while (len > k) { /* :220 */
+        /* :221 FindClosestClusters: rows in position (= creation id) order, strict '<' */
+        float min = FAST_MAXF;
+        int64_t bs = -1;
+        for (int64_t q = 0; q < S.nlive; ++q) {
+            const int64_t s = S.live[q];
+            if (S.rarg[s] < 0) continue;
+            if (S.rmin[s] < min || (S.rmin[s] == min && bs >= 0 && S.cid[s] < S.cid[bs])) {
+                min = S.rmin[s];
+                bs = s;
+            }
+        }
+        if (bs < 0 || !(min < FAST_MAXF)) break; /* :222-225 */
+        const int64_t sa = bs, sb = S.rarg[bs]; /* a = higher position (larger creation id) */
+
+        if (S.size[sa] + S.size[sb] > max_size) { /* :228-234 (only reachable with lazy_ban) */
+            S.Dm[sa * n + sb] = FAST_MAXF;
+            rescan_row(&S, sa);
+            ++skips;
+            continue;
+        }
+
+        if (merge_log) {
+            int64_t pi = 0, pj = 0; /* position = live clusters created earlier */
+            for (int64_t q = 0; q < S.nlive; ++q) {
+                const int64_t s = S.live[q];
+                pi += S.cid[s] < S.cid[sa];
+                pj += S.cid[s] < S.cid[sb];
+            }
+            merge_log[4 * merges + 0] = pi;
+            merge_log[4 * merges + 1] = pj;
+            merge_log[4 * merges + 2] = S.cid[sa];
+            merge_log[4 * merges + 3] = S.cid[sb];
+        }
+        if (merge_vals) merge_vals[merges] = min;
+        ++merges;
+
+        /* :237 MergeClusters(clusters[i], clusters[j]); the new cluster takes b's slot, a's slot is freed */
+        icl_ref_merge_centroid(S.cen + sa * d, S.size[sa], S.cen + sb * d, S.size[sb], d, S.cen + sb * d); /* elementwise: in place is safe */
+        next[tail[sa]] = head[sb];
+        head[sb] = head[sa];
+        /* tail[sb] stays */
+        S.size[sb] = S.size[sa] + S.size[sb];
+        S.size[sa] = 0;
+        for (int64_t q = 0; q < S.nlive; ++q)
+            if (S.live[q] == sa) {
+                S.live[q] = S.live[--S.nlive];
+                break;
+            }
+        S.cid[sb] = next_cid++;
+        len -= 1; /* two removed (:240), one appended (:241) */
+        const int64_t sc = sb;
+
+        /* :244 UpdateDistanceMatrix: the new last row from centroids (:81-93) */
+        float *row = S.Dm + sc * n;
+#pragma omp parallel for schedule(static)
+        for (int64_t q = 0; q < S.nlive; ++q) {
+            const int64_t t = S.live[q];
+            if (t != sc) row[t] = icl_ref_ward_distance(S.cen + t * d, S.size[t], S.cen + sc * d, S.size[sc], d); /* :84 */
+        }
+        rescan_row(&S, sc);
+        /* rows whose first minimum was one of the two removed columns (:100-116 deletes them) */
+        int64_t nre = 0;
+        for (int64_t q = 0; q < S.nlive; ++q) {
+            const int64_t s = S.live[q];
+            if (s != sc && (S.rarg[s] == sa || S.rarg[s] == sb)) redo[nre++] = s;
+        }
+#pragma omp parallel for schedule(dynamic, 4) if (nre > 8)
+        for (int64_t q = 0; q < nre; ++q) rescan_row(&S, redo[q]); /* rows are independent: each writes only its own cache */
+    }
+
+    /* :249-262 oversize handling is unreachable for max_size >= 1; flag instead of restating splitCluster */
+    int ret = 0;
+    for (int64_t s = 0; s < n; ++s)
+        if (S.size[s] > max_size) ret = 4;
+
+    /* :265-280 dense ids in position (creation id) order, dropping clusters below min_size */
+    for (int64_t i = 0; i < n; ++i) {
+        cluster_id[i] = -1;
+        member_rank[i] = -1;
+    }
+    int64_t *slot_of = (int64_t *)malloc((size_t)(2 * nn) * sizeof(int64_t)); /* creation id -> slot, -1 */
+    for (int64_t c = 0; c < 2 * nn; ++c) slot_of[c] = -1;
+    for (int64_t s = 0; s < n; ++s)
+        if (S.size[s]) slot_of[S.cid[s]] = s;
+    int32_t id = 0;
+    for (int64_t c = 0; c < 2 * nn; ++c) {
+        const int64_t s = slot_of[c];
+        if (s < 0 || S.size[s] < min_size) continue; /* :268-271 */
+        int32_t r = 0;
+        for (int64_t i = head[s]; i >= 0; i = next[i]) {
+            cluster_id[i] = id;
+            member_rank[i] = r++;
+        }
+        ++id;
+    }
+    *n_clusters = id;
+    if (n_merges) *n_merges = merges;
+    if (n_skips) *n_skips = skips;
+    free(S.live);
+    free(slot_of);
+    free(S.Dm);
+    free(S.cen);
+    free(S.cid);
+    free(S.size);
+    free(S.rmin);
+    free(S.rarg);
+    free(next);
+    free(redo);
+    free(head);
+    free(tail);
+    return ret;
+}

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from tests import ward_cases as WC
 
 pytestmark = pytest.mark.gpu
 
@@ -223,6 +224,110 @@ def test_cluster_runs_out_of_pairs(ctx):
 def test_cluster_mid_size_oracle_parity(ctx):
     # ~1.3e9 scan steps in the literal oracle: a few seconds
     same_as_oracle(ctx, mog(1200, 64, 42), 5, 50)
+
+
+# ---- beyond the literal oracle: oracle/ward_fast.c (pinned to ward_ref.c in tests/test_oracle_ward_fast.py) ----------------
+def same_as_fast_oracle(ctx, E, mn, mx):
+    f = O.cluster_fast(E, mn, mx, lazy_ban=False)
+    cid, rank, nc = ctx.cluster(E, mn, mx)
+    assert f["ok"]
+    m = ctx.last_merges()
+    assert len(m) == f["merges"], "number of merges"
+    want = f["log"][:, 2:4].astype(np.int32)
+    if not np.array_equal(m, want):
+        t = int(np.nonzero((m != want).any(axis=1))[0][0])
+        raise AssertionError("merge sequence differs first at merge %d: engine %s, oracle %s" % (t, m[t].tolist(), want[t].tolist()))
+    assert np.array_equal(ctx.last_merge_values().view(np.uint32), f["vals"].view(np.uint32)), "Ward values of the merged pairs"
+    assert np.array_equal(cid, f["cluster_id"]), "cluster ids differ"
+    assert np.array_equal(rank, f["member_rank"]), "member order differs"
+    assert nc == f["n_clusters"]
+    return f
+
+
+@pytest.mark.parametrize("name,E,mn,mx", WC.small_cases(), ids=[c[0] for c in WC.small_cases()])
+def test_every_small_case_against_both_oracles(ctx, name, E, mn, mx):
+    same_as_oracle(ctx, E, mn, mx)
+    same_as_fast_oracle(ctx, E, mn, mx)
+
+
+def test_large_n_creation_ids_past_40960(ctx):
+    """N=24 000, D=16, min=5 max=50: 21 360 merges, creation ids (rows of the packed triangle) up to 45 359.  The batched
+    update's spare workgroups once dropped rows >= 40 960 silently (16-iteration hit mask); ids, member order, the merge
+    log and every merge value must equal the oracle's."""
+    f = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
+    assert f["merges"] == 21360 and 24000 + f["merges"] > 40960
+
+
+def test_large_n_creation_ids_past_65536(ctx):
+    """N=45 000, D=8: 40 050 merges, creation ids up to 85 049 (past 2^16), 14.5 GB triangle."""
+    f = same_as_fast_oracle(ctx, WC.mog(45000, 8, 2), 5, 50)
+    assert f["merges"] == 40050
+
+
+def test_large_n_tie_heavy_integer_set(ctx):
+    """N=26 000 points on a 7^5 integer grid: thousands of exactly tied distances and duplicate points, so scan-order
+    tie-breaks (clustering.go:125 strict '<') decide most merges; creation ids reach ~49 000."""
+    f = same_as_fast_oracle(ctx, WC.ties(26000, 5, 4, levels=7), 5, 50)
+    assert 30000 + f["merges"] > 40960
+
+
+def test_large_n_tight_constraints(ctx):
+    """N=20 000, min=5 max=6: the loop ends with 'no pair left' handling of ~10^6 oversize pairs (static mask in the
+    engine, :228-234 in the reference)."""
+    same_as_fast_oracle(ctx, WC.mog(20000, 8, 3), 5, 6)
+
+
+def test_config2_full_size_properties_100k(ctx):
+    """BASELINE.json's metric size: N=100 000, D=2048, min=5 max=50 (k=11 000, 89 000 merges, 80 GB triangle).  No CPU
+    oracle reaches this size: size-independent properties + idempotence."""
+    import torch
+
+    n, d = 100000, 2048
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20250217)
+    cen = torch.randn((n // 20, d), generator=g, device="cuda")
+    lab = torch.randint(0, n // 20, (n,), generator=g, device="cuda")
+    E = (cen[lab] + 0.1 * torch.randn((n, d), generator=g, device="cuda")).contiguous()
+    del cen
+    torch.cuda.synchronize()
+    cid, rank, nc = ctx.cluster_dev(E.data_ptr(), n, d, 5, 50)
+    m = ctx.last_merges()
+    v = ctx.last_merge_values()
+    assert len(m) == 89000 == n - O.calc_optimal_clusters(n, 5, 50)[0]
+    kept = cid[cid >= 0]
+    counts = np.bincount(kept)
+    assert sorted(set(kept.tolist())) == list(range(nc)) and counts.min() >= 5 and counts.max() <= 50
+    order = np.lexsort((rank, cid))
+    o = order[cid[order] >= 0]
+    starts = np.r_[0, np.cumsum(counts)[:-1]]
+    assert np.array_equal(rank[o], np.arange(len(o)) - np.repeat(starts, counts))
+    # the merge log is a valid agglomeration over creation ids: both sides alive, a = the later-created one
+    alive = np.ones(n + len(m), bool)
+    alive[n:] = False
+    size = np.ones(n + len(m), np.int64)
+    for t, (a, b) in enumerate(m.tolist()):
+        assert a > b and alive[a] and alive[b], t
+        alive[a] = alive[b] = False
+        alive[n + t] = True
+        size[n + t] = size[a] + size[b]
+        assert size[n + t] <= 50
+    assert np.isfinite(v).all() and (v >= 0).all()
+    # spot-check merge values against the oracle's arithmetic: singleton-singleton merges can be recomputed from E alone
+    Eh = {}
+    checked = 0
+    for t, (a, b) in enumerate(m[:4000].tolist()):
+        if a < n and b < n:
+            for x in (a, b):
+                if x not in Eh:
+                    Eh[x] = E[x].cpu().numpy()
+            assert np.float32(v[t]).view(np.uint32) == O.ward_distance(Eh[a], 1, Eh[b], 1).view(np.uint32), t
+            checked += 1
+            if checked == 200:
+                break
+    assert checked > 50
+    # idempotence
+    cid2, rank2, nc2 = ctx.cluster_dev(E.data_ptr(), n, d, 5, 50)
+    assert nc2 == nc and np.array_equal(cid, cid2) and np.array_equal(rank, rank2) and np.array_equal(ctx.last_merges(), m)
 
 
 def test_context_reuse_different_shapes(ctx):
