@@ -14,6 +14,7 @@
 #pragma clang fp contract(off)
 
 #include "icl_common.h"
+#include "mfma_tile.h"
 
 #include <algorithm>
 #include <cmath>
@@ -30,7 +31,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_TIMER(stmt)
 #endif
 #ifndef WB_K
-#define WB_K 8 /* merges attempted per batched step; must be a power of two <= 16 (16 was measured twice: same total, the preselection and the finish kernel grow as fast as the update shrinks) */
+#define WB_K 16 /* merges attempted per batched step; a power of two <= 16.  With the first-generation update kernel (WB_K / 4 workgroups per slot block) 16 gained nothing over 8; with ward_update_batch2_kernel (one workgroup per block runs all chains from one fetch) N=100k takes 14.9 merges per step and the merge loop 2.27 s -> 1.87 s */
 static_assert((WB_K & (WB_K - 1)) == 0 && WB_K >= 4 && WB_K <= 16, "lane-indexed tables assume a power of two");
 #endif
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
@@ -1672,6 +1673,256 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Batched exact update, second generation ("one fetch per block").  ward_update_batch_kernel above splits the batch's
+// chains over WB_NH workgroups per 64-slot block, so every centroid column is fetched WB_NH times by the CUs (once from
+// HBM, then from the XCD's L2): at N = 100 000 the launch is bound by that per-CU fetch path (37 us per block pair and
+// round), not by HBM, and WB_K = 16 (four workgroups per block) gains nothing.  Here ONE workgroup per block runs ALL
+// chains from one pass over its 64 columns:
+//   * WX_L loader waves move the columns global -> LDS with LDS-DMA (no VGPR staging, no ds_write), WX_R stages of
+//     16 k-groups (16 KB) in a ring, WX_R-1 of them in flight (80 KB per CU at WX_R = 6), counted vmcnt + one raw
+//     barrier per stage;
+//   * WX_CW chain waves (two per SIMD), each running WX_CPW = WB_K / WX_CW in-order sums interleaved (the dependent
+//     add latency of one hides behind the other).  The new centroids ride the same ring (one more 1 KB piece per loader
+//     wave and stage: 16 chains x 16 k-groups x 16 B) and are read with broadcast ds_read_b128: all of a chain wave's
+//     operands are LDS reads, which return in order, so hipcc pipelines them with counted lgkmcnt waits.  (Measured and
+//     dropped: the centroids as scalar loads into SGPR operands -- SMEM returns out of order, every wait becomes
+//     lgkmcnt(0) and the s_load latency is exposed four times per stage: 57 us per block instead of 36.)
+// Arithmetic, row order, masks, keys and the dirty-column protocol are those of ward_update_batch_kernel.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef WX_R
+#define WX_R 6                         /* ring stages (16 KB each) */
+#endif
+#define WX_L 4                         /* loader waves */
+#define WX_CW 8                        /* chain waves */
+#define WX_CPW ((WB_K + WX_CW - 1) / WX_CW) /* chains per chain wave */
+#define WX_THREADS (64 * (WX_L + WX_CW))
+#define WX_XOPS (WB_SG / WX_L)         /* column pieces per loader wave and stage */
+#define WX_OPS (WX_XOPS + 1)           /* + one piece of new centroids: chains 4*pj .. 4*pj+3, 16 k-groups each */
+#define WX_NCH 16                      /* chains the centroid pieces always cover (cnew is allocated for 16) */
+#define WX_STAGE_F4 (WB_SG * 64 + WX_NCH * WB_SG) /* float4 per ring stage: columns, then [chain][k-group] centroids */
+static_assert(WB_SG == 16 && WB_SG % WX_L == 0, "a stage is 16 k-groups, dealt evenly to the loader waves");
+static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
+
+__global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+                                                                      const float *__restrict__ Crow, const float *__restrict__ cnewK,
+                                                                      int64_t cn_stride,
+                                                                      const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                                      const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                                      ward_state *__restrict__ st, int max_size, int64_t n,
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, int diag)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
+    // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
+    if (blockIdx.x < WB_R) {
+        float *sv = reinterpret_cast<float *>(wb_lds);
+        int *si = reinterpret_cast<int *>(sv + 16);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
+        return;
+    }
+    if (blockIdx.x == WB_R) {
+        float *sv = reinterpret_cast<float *>(wb_lds);
+        int *si = reinterpret_cast<int *>(sv + 16);
+        int *sh = si + 16;
+        WB_TIMER(const unsigned long long t0 = wall_clock64();)
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
+    const bool virt = blockIdx.x == WB_R + 1; // "virtual slots": lane i = tentative cluster c_i, column = its new centroid
+    const int64_t mblk = virt ? 0 : (int64_t)blockIdx.x - (WB_R + 2);
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    if (done || nb <= 0) return;
+    if (!virt && mblk * 64 >= nlive) return;
+    const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
+    int pa[WB_K], pb[WB_K], psc[WB_K];
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) {
+        pa[j] = st->B.a[j];
+        pb[j] = st->B.b[j];
+        psc[j] = st->B.sa[j] + st->B.sb[j];
+    }
+    const int64_t slot = virt ? lane : mblk * 64 + lane;
+    const int xraw = virt ? -1 : slot_id[slot];
+    // which rows does this lane's cluster take part in?
+    int x, sx;
+    if (virt) {
+        x = lane < nb ? (int)(n + t + lane) : -1;
+        sx = 0;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j)
+            if (lane == j) sx = psc[j];
+    } else {
+        x = slot < nlive ? xraw : -1;
+        sx = x >= 0 ? asz[x] : 0;
+    }
+    unsigned okmask = 0;
+    bool survives = false;
+    {
+        bool alive = x >= 0 && sx > 0;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j) {
+            if (j < nb) {
+                if (virt) {
+                    if (alive && lane < j && sx + psc[j] <= max_size) okmask |= 1u << j;
+                } else {
+                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
+                }
+            }
+        }
+        survives = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
+    }
+    // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
+    // streams its centroid from the row-major copy instead and the column is re-made on the way
+    bool dirty_lane = false;
+    const int nd = virt ? 0 : dirty_n0;
+    for (int z = 0; z < nd; ++z) dirty_lane |= __shfl(dirty_s0, z, 64) == (int)slot;
+    const int dq_real = d >> 2;
+    const bool any_dirty = __any(dirty_lane);
+    if (!__any(okmask != 0)) {
+        // nothing to compute here, but a stale column must not outlive this step's dirty list
+        unsigned long long dm = __ballot(dirty_lane);
+        while (dm) {
+            const int l = __ffsll((long long)dm) - 1;
+            dm &= dm - 1;
+            const int64_t sl = mblk * 64 + l;
+            for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
+                *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
+        }
+        return;
+    }
+    const int nstage = dqp / WB_SG;
+    const bool loader = wave >= WX_CW;
+    const int pj = wave - WX_CW; // loader index
+    const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
+    const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot * 16;
+    const int64_t row_bytes = virt ? 16 : S * 16;
+    const unsigned ring_base = lds_addr_of(wb_lds);
+    // lane l of loader pj fetches k-group (stage*16 + l%16) of chain 4*pj + l/16 for the centroid piece
+    const char *csrc = reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * (pj & 3) + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
+    auto issue = [&](int stage) { // this loader wave's WX_OPS pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
+        const int g0 = stage * WB_SG + pj * WX_XOPS;
+        const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
+#pragma unroll
+        for (int q = 0; q < WX_XOPS; ++q) {
+            const int g = g0 + q;
+            const char *src = ctb + (int64_t)g * row_bytes + voff;
+            if (dirty_lane && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot * d + (int64_t)g * 4) * 4;
+            glds16_asm(src, sbase + (unsigned)((pj * WX_XOPS + q) * 1024));
+        }
+        glds16_asm(csrc + (int64_t)stage * (WB_SG * 16), sbase + (unsigned)(WB_SG * 1024 + pj * 1024));
+    };
+    const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
+    if (loader && do_load)
+        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i);
+    // the chain waves' new centroids: wave-uniform addresses -> scalar loads
+    const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * WX_CPW : 0);
+    const int jB = __builtin_amdgcn_readfirstlane(jA + (WX_CPW - 1));
+    const bool chain = wave < WX_CW && jA < nb;
+    float sA = 0.0f, sB = 0.0f;
+    auto consume = [&](int stage) {
+        const float4 *xr = wb_lds + (stage % WX_R) * WX_STAGE_F4 + lane;
+        const float4 *ca = wb_lds + (stage % WX_R) * WX_STAGE_F4 + WB_SG * 64 + jA * WB_SG; // wave-uniform: broadcast reads
+        const float4 *cb = wb_lds + (stage % WX_R) * WX_STAGE_F4 + WB_SG * 64 + jB * WB_SG;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 xv[WB_SG / 2];
+#pragma unroll
+            for (int g = 0; g < WB_SG / 2; ++g) xv[g] = xr[(h * (WB_SG / 2) + g) * 64];
+#pragma unroll
+            for (int g = 0; g < WB_SG / 2; ++g) {
+                const float4 c0 = ca[h * (WB_SG / 2) + g];
+                const f2 xa = {xv[g].x, xv[g].y}, xb = {xv[g].z, xv[g].w};
+                const f2 a0 = {c0.x, c0.y}, a1 = {c0.z, c0.w};
+                const f2 da = xa - a0, db = xb - a1; // clustering.go:139 via :84
+                const f2 qa = da * da, qb = db * db; // :154 products, each rounded
+                if (WX_CPW == 2) {
+                    const float4 c1 = cb[h * (WB_SG / 2) + g];
+                    const f2 b0 = {c1.x, c1.y}, b1 = {c1.z, c1.w};
+                    const f2 ea = xa - b0, eb = xb - b1;
+                    const f2 ra = ea * ea, rb = eb * eb;
+                    sA = sA + qa.x; // :154 the running sums, each strictly in k order; the two chains alternate
+                    sB = sB + ra.x;
+                    sA = sA + qa.y;
+                    sB = sB + ra.y;
+                    sA = sA + qb.x;
+                    sB = sB + rb.x;
+                    sA = sA + qb.y;
+                    sB = sB + rb.y;
+                } else {
+                    sA = sA + qa.x;
+                    sA = sA + qa.y;
+                    sA = sA + qb.x;
+                    sA = sA + qb.y;
+                }
+            }
+        }
+    };
+    for (int i = 0; i < nstage; ++i) {
+        if (loader) {
+            // stage i has landed once at most the WX_R-2 younger stages are outstanding (in the tail nothing new is issued:
+            // wait for everything, those stages have been in flight all along)
+            if (i + WX_R - 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * WX_OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of stage i-1 have returned before its ring slot is refilled
+        }
+        __builtin_amdgcn_s_barrier();
+        if (loader) {
+            if (any_dirty && i >= 2) { // re-make the dirty columns from the stage that has just landed (rare)
+                const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + lane;
+#pragma unroll
+                for (int q = 0; q < WX_XOPS; ++q) {
+                    const int g = i * WB_SG + pj * WX_XOPS + q;
+                    if (dirty_lane && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot)) = xr[(pj * WX_XOPS + q) * 64];
+                }
+            }
+            if (i + WX_R - 1 < nstage && do_load) issue(i + WX_R - 1); // into the slot stage i-1 was read from: every chain wave is past this barrier
+        } else if (chain && do_chain) {
+            consume(i);
+        }
+    }
+    if (!chain) return;
+#pragma unroll
+    for (int cc = 0; cc < WX_CPW; ++cc) {
+        const int j = jA + cc;
+        if (j >= nb) break;
+        const float s = cc ? sB : sA;
+        unsigned long long key = ~0ull;
+        if ((okmask >> j) & 1u) {
+            int sc = psc[0];
+#pragma unroll
+            for (int q = 1; q < WB_K; ++q)
+                if (j == q) sc = psc[q];
+            const float num = (float)((int64_t)sx * (int64_t)sc);
+            const float den = (float)(sx + sc);
+            const float val = (num / den) * s;
+            const int64_t c = n + t + j;
+            Dtri[rowoff[c] + x] = val;
+            if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+        }
+        // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the validation
+        // needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's cache after a full commit
+        unsigned long long key2 = survives ? key : ~0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o < key ? o : key;
+            const unsigned long long o2 = __shfl_down(key2, off, 64);
+            key2 = o2 < key2 ? o2 : key2;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
+        if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
+        WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
+        WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
+    }
+}
+
 // FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
 // (see ward_update_lw_kernel) instead of centroid recomputes -- 12 bytes of reads per live cluster and merge, so the
 // launch is as long as its preselection.  Same grid roles as ward_update_batch_kernel (spare re-minimisers, the
@@ -2570,8 +2821,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         ICL_HIP(ctx, hipMemsetAsync(w->CT, 0, (size_t)(4 * ngrp * w->S) * sizeof(float), ctx->stream));
         WS_ALLOC(Crow, float, dd * w->S);
         w->cn_stride = 4 * std::max<int64_t>(ngrp, wb_groups((int)dd) + WB_PAD_G);
-        WS_ALLOC(cnew, float, WB_K * w->cn_stride);
-        ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(WB_K * w->cn_stride) * sizeof(float), ctx->stream));
+        WS_ALLOC(cnew, float, 16 * w->cn_stride); // 16 images whatever WB_K is: the update kernel's centroid pieces always cover 16 chains
+        ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
         WS_ALLOC(slot_id, int32_t, w->S);
         WS_ALLOC(id_slot, int32_t, w->M);
         WS_ALLOC(asz, int32_t, w->M);
@@ -2892,6 +3143,22 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             wb_attr = true;
         }
         const unsigned wb_blocks = (unsigned)((w->S / 64 + 7) / 8 * 8) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
+        // ICL_WARD_UPD=1 selects the first-generation kernel (WB_NH workgroups per slot block) for A/B measurements
+        static const bool gen2 = [] {
+            const char *e = getenv("ICL_WARD_UPD");
+            return !(e && e[0] == '1');
+        }();
+        const size_t wx_lds_bytes = (size_t)WX_R * WX_STAGE_F4 * 16;
+        static const int wx_diag = [] { // ICL_WX_DIAG: 1 = no chain arithmetic, 2 = no column loads (kernel timing experiments; WRONG results)
+            const char *e = getenv("ICL_WX_DIAG");
+            return e ? atoi(e) : 0;
+        }();
+        const unsigned wx_blocks = (unsigned)(w->S / 64) + 2 + WB_R;
+        static bool wx_attr = false;
+        if (!wx_attr) {
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            wx_attr = true;
+        }
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0);
@@ -2902,8 +3169,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                                    w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
                 return;
             }
-            hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow, w->cnew,
-                               w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+            if (gen2)
+                hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+                                   w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag);
+            else
+                hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+                                   w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
         };
         auto step_b = [&](bool prof) {
             if (prof) {

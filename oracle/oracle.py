@@ -31,7 +31,13 @@ def lib():
     srcs = [os.path.join(_HERE, f) for f in ("ward_ref.c", "ward_fast.c", "resnet_ref.c")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s)):
         build()
+    # team size of the OpenMP regions (ward_fast.c, resnet_ref.c): this job's CPU share, not the host's thread count
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     L = C.CDLL(_SO)
+    L.icl_fast_set_threads.restype = None
+    L.icl_fast_set_threads.argtypes = [C.c_int]
+    L.icl_fast_set_threads(int(os.environ.get("OMP_NUM_THREADS", cores)))
     L.icl_ref_dot.restype = C.c_float
     L.icl_ref_dot.argtypes = [f32p, f32p, C.c_int64]
     L.icl_ref_ward_distance.restype = C.c_float

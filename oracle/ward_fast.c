@@ -34,6 +34,7 @@
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
  */
 #include <float.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,6 +44,11 @@
 float icl_ref_ward_distance(const float *ca, int64_t sa, const float *cb, int64_t sb, int64_t d); /* ward_ref.c */
 void icl_ref_merge_centroid(const float *ca, int64_t sa, const float *cb, int64_t sb, int64_t d, float *out);
 int icl_ref_calc_optimal_clusters(int64_t total, int64_t min_size, int64_t max_size, int64_t *k);
+
+/* The OpenMP team: a GPU box shares its host with other jobs and exposes far more hardware threads than this job's CPU
+ * share, so the caller pins the team size (oracle.py: min(affinity, 16)); an oversubscribed team spins in every one of
+ * the ~10^5 parallel regions of a large run. */
+void icl_fast_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 typedef struct {
     int64_t n, d, max_size;
