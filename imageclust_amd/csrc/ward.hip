@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 int icl_dist_mfma_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, float *d_out, const int64_t *d_rowoff, int64_t ld); // distance_mfma.hip
 
@@ -36,6 +37,9 @@ static_assert((WB_K & (WB_K - 1)) == 0 && WB_K >= 4 && WB_K <= 16, "lane-indexed
 #endif
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
 #define WB_RM 4 /* rows each of them takes (matches wg, wg + WB_R, ...): hub clusters leave hundreds of rows dirty */
+#define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 192 are re-minimised per step; the rest stays lazy) */
+#define WB_WTOP 5    /* keys a wave / a slice reports before its sentinel */
+#define WB_PA_KEYS (WB_WTOP + 1)
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
     int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
@@ -57,6 +61,10 @@ struct ward_batch_state {
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
+    // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
+    int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
+    int32_t pa_rows[WB_R][WB_PA_CAP];              // rows of the slice whose cached partner is a member of the batch
+    unsigned long long pa_keys[WB_R][WB_PA_KEYS];  // the slice's smallest (value,row) keys in ascending order, then a sentinel
 };
 
 struct ward_state {
@@ -455,7 +463,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         st->B.epoch = 1;
         st->B.dirty_n = 0;
         st->B.ov_n = 0;
-        for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = 0;
+        for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
@@ -961,7 +969,6 @@ static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 
 // shuffles and appends a SENTINEL (a lower bound for everything it did not report); wave 0 then walks the <= 50
 // entries in ascending order and stops at the first sentinel, so whatever it saw before is exact.
 #define WB_MAXOV 8
-#define WB_WTOP 5
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 {
 #pragma unroll
@@ -1025,17 +1032,49 @@ __device__ __forceinline__ void scan_row_ex(const float *__restrict__ row, int64
     }
 }
 
-// Spare workgroup i of the batched update: rows whose cached partner is a member of the tentative batch will be dirty
-// once it commits.  Every spare workgroup enumerates them in the same deterministic order, takes the i-th and
-// re-minimises it without the batch's members; the finish kernel installs the results if the whole batch commits and
-// the preselection (a later workgroup of the same grid) waits for the ones it needs instead of scanning itself.
+// Pops the WB_WTOP smallest keys of a wave (every lane offers k1 < k2, its two smallest; a key with bit 0 set is a SENTINEL:
+// a lower bound of entries that are not listed) into out[0..WB_WTOP), then out[WB_WTOP] = a sentinel for whatever the wave
+// did not report.  A reader that walks such streams in ascending order and stops at the first sentinel has seen every key
+// below it.  Keys are unique (one per row).
+// has_rest: the lane has seen more entries than the two it offers (its own sentinel k2|1 follows k2); ntop keys are popped.
+__device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned long long k2, bool has_rest, unsigned long long *out, int ntop, int lane)
+{
+    unsigned long long head = k1;
+    int stg = 0; // 0: head = k1, 1: head = k2, 2: head = sentinel(k2)
+    bool ended = false;
+    for (int q = 0; q < ntop; ++q) {
+        const unsigned long long m = ended ? ~0ull : wave_min_u64(head);
+        if (lane == 0) out[q] = m;
+        if (m == ~0ull || (m & 1ull)) { // nothing left / a lane ran out of known entries: the wave's list ends here
+            ended = true;
+            continue;
+        }
+        if (head == m) {
+            ++stg;
+            head = stg == 1 ? k2 : ((k2 == ~0ull || !has_rest) ? ~0ull : (k2 | 1ull));
+        }
+    }
+    const unsigned long long rest = ended ? ~0ull : wave_min_u64(head);
+    if (lane == 0) out[ntop] = rest == ~0ull ? rest : (rest | 1ull);
+}
+
+// Spare workgroups of the batched update (the first WB_R workgroups of the grid, so they are resident before any other).
+// Phase A: workgroup wg scans slice wg of the row caches (rows [0, n+t) cut into WB_R runs) ONCE for two things:
+//   - the rows whose cached partner is a member of the tentative batch (they will be dirty once it commits) -> pa_rows,
+//   - the slice's WB_WTOP smallest (value,row) keys + a sentinel -> pa_keys: the preselection merges WB_R short streams
+//     instead of scanning n+t row caches with one workgroup (92 us of every step at N = 100 000).
+// Phase B (after all slices are published): the matched rows are dealt round-robin in slice order; workgroup wg takes
+// entries wg, wg + WB_R, ... (WB_RM of them), re-minimises each without the batch's members and publishes the result.
+// The finish kernel installs them if the whole batch commits; the preselection waits for the ones it needs.
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                  int max_size, ward_state *__restrict__ st, float *sv, int *si)
 {
     __shared__ int excl[2 * WB_K];
-    __shared__ int wcnt[16];
+    __shared__ int lcnt;
+    __shared__ int lrows[WB_PA_CAP];
     __shared__ int mine[WB_RM];
+    __shared__ unsigned long long wstream[16 * WB_PA_KEYS];
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
     if (nb <= 0 || t0 + nb >= st->target) return;
@@ -1043,63 +1082,88 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         const int j = threadIdx.x >> 1;
         excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
     }
+    if (threadIdx.x == 0) lcnt = 0;
     __syncthreads();
     int ex[2 * WB_K];
 #pragma unroll
     for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    // enumerate: thread-strided over int4 groups of rownn; a thread's matches keep their row order
-    const int64_t nvec = (n + t0 + 3) >> 2;
-    int cnt = 0;
-    int hrow0 = -1, hrow1 = -1, hrow2 = -1, hrow3 = -1; // the thread's first four matches, in row order (any n)
-    {
-        for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x) {
-            const int4 nn4 = reinterpret_cast<const int4 *>(rownn)[q];
-            const int nnv[4] = {nn4.x, nn4.y, nn4.z, nn4.w};
+    // ---- phase A: one pass over this workgroup's slice (int4 groups of rownn / float4 groups of rowmin)
+    const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32 / -1
+    const int64_t per = (nvec + WB_R - 1) / WB_R;
+    const int64_t q_lo = (int64_t)wg * per, q_hi = (q_lo + per < nvec ? q_lo + per : nvec);
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    int nseen = 0;
+    for (int64_t q = q_lo + threadIdx.x; q < q_hi; q += blockDim.x) {
+        const int4 nn4 = reinterpret_cast<const int4 *>(rownn)[q];
+        const float4 v4 = reinterpret_cast<const float4 *>(rowmin)[q];
+        const int nnv[4] = {nn4.x, nn4.y, nn4.z, nn4.w};
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bool m = false;
+        for (int e = 0; e < 4; ++e) {
+            if (!(vv[e] < ICL_MAXF)) continue; // dead rows and rows being created hold MaxFloat32
+            const int r = (int)(q * 4 + e);
+            bool self = false, dep = false;
 #pragma unroll
-                for (int z = 0; z < 2 * WB_K; ++z) m |= (nnv[e] >= 0) & (nnv[e] == ex[z]);
-                if (m) {
-                    const int r = (int)(q * 4 + e);
-                    bool self = false;
-#pragma unroll
-                    for (int z = 0; z < 2 * WB_K; ++z) self |= r == ex[z];
-                    if (!self && rowmin[r] < ICL_MAXF) { // alive rows only (dead rows hold MaxFloat32)
-                        if (cnt == 0) hrow0 = r;
-                        else if (cnt == 1) hrow1 = r;
-                        else if (cnt == 2) hrow2 = r;
-                        else if (cnt == 3) hrow3 = r;
-                        ++cnt;
-                    }
-                }
+            for (int z = 0; z < 2 * WB_K; ++z) {
+                self |= r == ex[z];
+                dep |= (nnv[e] >= 0) & (nnv[e] == ex[z]);
             }
+            if (self) continue; // the batch's own members are dead if it commits
+            if (dep) {
+                const int at = atomicAdd(&lcnt, 1);
+                if (at < WB_PA_CAP) lrows[at] = r; // beyond the cap: left to the lazy path (exact, just later)
+            }
+            const unsigned long long k = ((unsigned long long)__float_as_uint(vv[e]) << 32) | ((unsigned)r << 1);
+            ++nseen;
+            if (k < k1) {
+                k2 = k1;
+                k1 = k;
+            } else if (k < k2)
+                k2 = k;
         }
     }
-    // exclusive prefix over threads
-    int inc = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wcnt[wave] = inc;
+    wave_pop_top(k1, k2, nseen > 2, &wstream[wave * WB_PA_KEYS], WB_WTOP, lane);
     __syncthreads();
-    int base = 0;
-    for (int w2 = 0; w2 < wave; ++w2) base += wcnt[w2];
-    const int first = base + inc - cnt;
-    if (wg == 0 && threadIdx.x == blockDim.x - 1) st->B.sum_dep += (unsigned long long)(first + cnt); // statistics: rows depending on the batch
-    // the matches with global index wg, wg + WB_R, ... are mine (concurrent write-backs by the preselection may make two
-    // workgroups disagree on the enumeration: every workgroup therefore publishes the rows it actually scanned)
-    if (threadIdx.x < WB_RM) mine[threadIdx.x] = -1;
-    __syncthreads();
-    {
-        const int hr[4] = {hrow0, hrow1, hrow2, hrow3};
+    if (wave == 0) {
+        // merge the nwave streams (<= 16 * 6 = 96 entries): each lane offers up to two entries, smaller first
+        const int tot = nwave * WB_PA_KEYS;
+        unsigned long long e1 = lane < tot ? wstream[lane] : ~0ull, e2 = lane + 64 < tot ? wstream[lane + 64] : ~0ull;
+        if (e2 < e1) {
+            const unsigned long long tmp = e1;
+            e1 = e2;
+            e2 = tmp;
+        }
+        // (an entry that is itself a sentinel ends the merged stream when it reaches the head: wave_pop_top tests bit 0)
+        wave_pop_top(e1, e2, false, st->B.pa_keys[wg], WB_WTOP, lane);
+        const int c = lcnt < WB_PA_CAP ? lcnt : WB_PA_CAP;
+        if (lane < c) st->B.pa_rows[wg][lane] = lrows[lane];
+        if (lane == 0) st->B.pa_cnt[wg] = c;
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(&st->B.pa_flag[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- barrier over the WB_R spare workgroups (all resident: they are the first workgroups of the grid)
+        int ok = lane >= WB_R;
+        for (int spin = 0; spin < 200000 && !__all(ok); ++spin) {
+            if (!ok) ok = __hip_atomic_load(&st->B.pa_flag[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+            if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
+        }
+        // ---- phase B assignment: global index of a matched row = matches of earlier slices + its position
+        int cnt_l = (lane < WB_R && ok) ? __hip_atomic_load(&st->B.pa_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (!__all(ok)) cnt_l = 0; // a slice is missing (cannot happen on a healthy device): nothing speculative this step
+        int inc = cnt_l;
 #pragma unroll
-        for (int z = 0; z < 4; ++z) { // a thread's fifth and later matches are left to the lazy path
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        const int first = inc - cnt_l, total = __shfl(inc, 63, 64);
+        if (wg == 0 && lane == 0) st->B.sum_dep += (unsigned long long)total; // statistics: rows depending on the batch
+        if (lane < WB_RM) mine[lane] = -1;
+        // lane l (slice l) owns global indices [first, first + cnt_l): hand out those congruent to wg mod WB_R
+        for (int z = 0; z < cnt_l; ++z) {
             const int idx = first + z;
-            if (z < cnt && idx >= wg && (idx - wg) % WB_R == 0 && (idx - wg) / WB_R < WB_RM) mine[(idx - wg) / WB_R] = hr[z];
+            if (idx >= wg && (idx - wg) % WB_R == 0 && (idx - wg) / WB_R < WB_RM)
+                mine[(idx - wg) / WB_R] = __hip_atomic_load(&st->B.pa_rows[lane][z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1130,7 +1194,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     __shared__ int excl[2 * WB_K];
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
     __shared__ int cmd[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, target = st->target;
     const int t_after = t0 + nb;
@@ -1150,64 +1214,35 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     int ex[2 * WB_K];
 #pragma unroll
     for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
-    // ---- one pass: per-lane two smallest (value,row) keys; the batch's own members are skipped (dead if it commits)
-    unsigned long long k1 = ~0ull, k2 = ~0ull;
-    const int nsw = nwave < 64 / (WB_WTOP + 1) ? nwave : 64 / (WB_WTOP + 1); // scanning waves: their streams fit one wave
-    const int nst = nsw * 64;
-    if (wave < nsw) {
-        const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32
-        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)nst) {
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * nst;
-                v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * nst;
-                const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (e[i] < ICL_MAXF) {
-                        const unsigned r = (unsigned)(q * 4 + i);
-                        const unsigned long long k = ((unsigned long long)__float_as_uint(e[i]) << 32) | (r << 1);
-                        if (k < k2) {
-                            bool hit = false;
-#pragma unroll
-                            for (int z = 0; z < 2 * WB_K; ++z) hit |= ex[z] == (int)r;
-                            if (!hit) {
-                                if (k < k1) {
-                                    k2 = k1;
-                                    k1 = k;
-                                } else
-                                    k2 = k;
-                            }
-                        }
-                    }
-                }
-            }
+    // ---- the row caches were scanned by the spare workgroups (one slice each): merge their WB_R streams of WB_PA_KEYS entries
+    const int epoch0 = st->B.epoch;
+    if (wave == 0) {
+        int ok = lane >= WB_R;
+        for (int spin = 0; spin < 200000 && !__all(ok); ++spin) {
+            if (!ok) ok = __hip_atomic_load(&st->B.pa_flag[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch0;
+            if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
         }
+        if (lane == 0) cmd[3] = __all(ok) ? 1 : 0;
     }
-    // ---- per wave: pop the WB_WTOP smallest, then a sentinel = lower bound of the rest of the wave
+    __syncthreads();
+    const bool have_streams = cmd[3] != 0;
+    constexpr int tot_e = WB_R * WB_PA_KEYS; // 288 entries
+    constexpr int nsw = 4;                   // merging waves: two entries per lane, WB_PTOP keys + a sentinel out of each
+    constexpr int WB_PTOP = 64 / nsw - 1;    // 15: the walker below holds one entry per lane (64)
+    static_assert(tot_e <= nsw * 128, "two entries per lane");
     if (wave < nsw) {
-        unsigned long long head = k1;
-        int stg = 0; // 0: head = k1, 1: head = k2, 2: head = sentinel(k2)
-        bool ended = false;
-        for (int q = 0; q < WB_WTOP; ++q) {
-            const unsigned long long m = ended ? ~0ull : wave_min_u64(head);
-            if (lane == 0) wstream[wave * (WB_WTOP + 1) + q] = m;
-            if (m == ~0ull || (m & 1ull)) { // nothing left / a lane ran out of known entries: the wave's list ends here
-                ended = true;
-                continue;
-            }
-            if (head == m) { // keys are unique (distinct rows)
-                ++stg;
-                head = stg == 1 ? k2 : (k2 == ~0ull ? ~0ull : (k2 | 1ull));
-            }
+        const int e = wave * 128 + lane;
+        unsigned long long e1 = ~0ull, e2 = ~0ull;
+        if (have_streams && e < tot_e)
+            e1 = __hip_atomic_load(&st->B.pa_keys[e / WB_PA_KEYS][e % WB_PA_KEYS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have_streams && e + 64 < tot_e)
+            e2 = __hip_atomic_load(&st->B.pa_keys[(e + 64) / WB_PA_KEYS][(e + 64) % WB_PA_KEYS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e2 < e1) {
+            const unsigned long long tmp = e1;
+            e1 = e2;
+            e2 = tmp;
         }
-        const unsigned long long rest = ended ? ~0ull : wave_min_u64(head);
-        if (lane == 0) wstream[wave * (WB_WTOP + 1) + WB_WTOP] = rest == ~0ull ? rest : (rest | 1ull);
+        wave_pop_top(e1, e2, false, &wstream[wave * (WB_PTOP + 1)], WB_PTOP, lane);
     }
     __syncthreads();
     // ---- wave 0 owns the candidate list (one entry per lane) and resolves it; rescans use the whole workgroup
@@ -1215,7 +1250,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     int nn = -1, nsz = 0, rsz = 0;
     bool nn_alive = false;
     if (wave == 0) {
-        if (lane < nsw * (WB_WTOP + 1)) key = wstream[lane];
+        if (lane < nsw * (WB_PTOP + 1)) key = wstream[lane];
         if (key != ~0ull && !(key & 1ull)) {
             const int r = (int)((key & 0xffffffffull) >> 1);
             nn = rownn[r];
@@ -1691,16 +1726,22 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 // Arithmetic, row order, masks, keys and the dirty-column protocol are those of ward_update_batch_kernel.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef WX_R
-#define WX_R 6                         /* ring stages (16 KB each) */
+#define WX_R 4                         /* ring stages (20 KB each: 16 KB of columns + 4 KB of centroids); depth 4..7 measured within 2 % of each other */
 #endif
-#define WX_L 4                         /* loader waves */
+#ifndef WX_L
+#define WX_L 4                         /* loader waves (4 or 2) */
+#endif
 #define WX_CW 8                        /* chain waves */
 #define WX_CPW ((WB_K + WX_CW - 1) / WX_CW) /* chains per chain wave */
 #define WX_THREADS (64 * (WX_L + WX_CW))
 #define WX_XOPS (WB_SG / WX_L)         /* column pieces per loader wave and stage */
-#define WX_OPS (WX_XOPS + 1)           /* + one piece of new centroids: chains 4*pj .. 4*pj+3, 16 k-groups each */
+#define WX_COPS (4 / WX_L)             /* centroid pieces per loader wave and stage (4 pieces: chains 4p .. 4p+3, 16 k-groups each) */
+#define WX_OPS (WX_XOPS + WX_COPS)
 #define WX_NCH 16                      /* chains the centroid pieces always cover (cnew is allocated for 16) */
-#define WX_STAGE_F4 (WB_SG * 64 + WX_NCH * WB_SG) /* float4 per ring stage: columns, then [chain][k-group] centroids */
+#ifndef WX_NS
+#define WX_NS 1                        /* sets of 64 slots per workgroup (they share the centroid reads and the per-workgroup overhead).  Measured: 2 sets = 89 us per 128 slots against 47.7 us per 64 -- the chain waves are VALU-issue bound (8 instructions per chain and k-group at 4 cycles each: 27 us floor per 64 slots and 16 chains), so sharing LDS reads buys 6 % at N=100k and costs 30 % at N=10k (half as many workgroups) */
+#endif
+#define WX_STAGE_F4 (WX_NS * WB_SG * 64 + WX_NCH * WB_SG) /* float4 per ring stage: WX_NS sets of columns, then [chain][k-group] centroids */
 static_assert(WB_SG == 16 && WB_SG % WX_L == 0, "a stage is 16 k-groups, dealt evenly to the loader waves");
 static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
 
@@ -1737,7 +1778,9 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     const int64_t mblk = virt ? 0 : (int64_t)blockIdx.x - (WB_R + 2);
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     if (done || nb <= 0) return;
-    if (!virt && mblk * 64 >= nlive) return;
+    // A workgroup owns WX_NS sets of 64 consecutive slots (the virtual-slot workgroup: one set).  The sets share every
+    // centroid read and the per-launch overhead; a set beyond the live range is simply inactive.
+    if (!virt && mblk * (64 * WX_NS) >= nlive) return;
     const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
     int pa[WB_K], pb[WB_K], psc[WB_K];
 #pragma unroll
@@ -1746,53 +1789,62 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         pb[j] = st->B.b[j];
         psc[j] = st->B.sa[j] + st->B.sb[j];
     }
-    const int64_t slot = virt ? lane : mblk * 64 + lane;
-    const int xraw = virt ? -1 : slot_id[slot];
-    // which rows does this lane's cluster take part in?
-    int x, sx;
-    if (virt) {
-        x = lane < nb ? (int)(n + t + lane) : -1;
-        sx = 0;
+    int64_t slot[WX_NS];
+    int x[WX_NS], sx[WX_NS];
+    unsigned okmask[WX_NS];
+    bool survives[WX_NS], dirty_lane[WX_NS], set_on[WX_NS];
+    const int dq_real = d >> 2;
+    bool any_ok = false, any_dirty = false;
 #pragma unroll
-        for (int j = 0; j < WB_K; ++j)
-            if (lane == j) sx = psc[j];
-    } else {
-        x = slot < nlive ? xraw : -1;
-        sx = x >= 0 ? asz[x] : 0;
-    }
-    unsigned okmask = 0;
-    bool survives = false;
-    {
-        bool alive = x >= 0 && sx > 0;
+    for (int u = 0; u < WX_NS; ++u) {
+        slot[u] = virt ? lane : (mblk * WX_NS + u) * 64 + lane;
+        set_on[u] = virt ? u == 0 : (mblk * WX_NS + u) * 64 < nlive; // wave-uniform
+        // which rows does this lane's cluster take part in?
+        if (virt) {
+            x[u] = (u == 0 && lane < nb) ? (int)(n + t + lane) : -1;
+            sx[u] = 0;
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j)
+                if (lane == j) sx[u] = psc[j];
+        } else {
+            const int xraw = set_on[u] ? slot_id[slot[u]] : -1;
+            x[u] = slot[u] < nlive ? xraw : -1;
+            sx[u] = x[u] >= 0 ? asz[x[u]] : 0;
+        }
+        okmask[u] = 0;
+        bool alive = x[u] >= 0 && sx[u] > 0;
 #pragma unroll
         for (int j = 0; j < WB_K; ++j) {
             if (j < nb) {
                 if (virt) {
-                    if (alive && lane < j && sx + psc[j] <= max_size) okmask |= 1u << j;
+                    if (alive && lane < j && sx[u] + psc[j] <= max_size) okmask[u] |= 1u << j;
                 } else {
-                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
-                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
+                    alive = alive && x[u] != pa[j] && x[u] != pb[j]; // members of p_0..p_j are gone when c_j is created
+                    if (alive && sx[u] + psc[j] <= max_size) okmask[u] |= 1u << j;
                 }
             }
         }
-        survives = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
+        survives[u] = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
+        // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
+        // streams its centroid from the row-major copy instead and the column is re-made on the way
+        dirty_lane[u] = false;
+        const int nd = (virt || !set_on[u]) ? 0 : dirty_n0;
+        for (int z = 0; z < nd; ++z) dirty_lane[u] |= __shfl(dirty_s0, z, 64) == (int)slot[u];
+        any_ok |= __any(okmask[u] != 0);
+        any_dirty |= __any(dirty_lane[u]);
     }
-    // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
-    // streams its centroid from the row-major copy instead and the column is re-made on the way
-    bool dirty_lane = false;
-    const int nd = virt ? 0 : dirty_n0;
-    for (int z = 0; z < nd; ++z) dirty_lane |= __shfl(dirty_s0, z, 64) == (int)slot;
-    const int dq_real = d >> 2;
-    const bool any_dirty = __any(dirty_lane);
-    if (!__any(okmask != 0)) {
+    if (!any_ok) {
         // nothing to compute here, but a stale column must not outlive this step's dirty list
-        unsigned long long dm = __ballot(dirty_lane);
-        while (dm) {
-            const int l = __ffsll((long long)dm) - 1;
-            dm &= dm - 1;
-            const int64_t sl = mblk * 64 + l;
-            for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
-                *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
+#pragma unroll
+        for (int u = 0; u < WX_NS; ++u) {
+            unsigned long long dm = __ballot(dirty_lane[u]);
+            while (dm) {
+                const int l = __ffsll((long long)dm) - 1;
+                dm &= dm - 1;
+                const int64_t sl = (mblk * WX_NS + u) * 64 + l;
+                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
+                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
+            }
         }
         return;
     }
@@ -1800,86 +1852,114 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     const bool loader = wave >= WX_CW;
     const int pj = wave - WX_CW; // loader index
     const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
-    const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot * 16;
     const int64_t row_bytes = virt ? 16 : S * 16;
     const unsigned ring_base = lds_addr_of(wb_lds);
-    // lane l of loader pj fetches k-group (stage*16 + l%16) of chain 4*pj + l/16 for the centroid piece
-    const char *csrc = reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * (pj & 3) + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
-    auto issue = [&](int stage) { // this loader wave's WX_OPS pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
+    // lane l of loader pj fetches k-group (stage*16 + l%16) of chain 4*(piece) + l/16 for its centroid piece(s)
+    const char *csrc = reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * WX_COPS * (pj & (WX_L - 1)) + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
+    auto issue = [&](int stage) { // this loader wave's pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
         const int g0 = stage * WB_SG + pj * WX_XOPS;
         const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
 #pragma unroll
-        for (int q = 0; q < WX_XOPS; ++q) {
-            const int g = g0 + q;
-            const char *src = ctb + (int64_t)g * row_bytes + voff;
-            if (dirty_lane && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot * d + (int64_t)g * 4) * 4;
-            glds16_asm(src, sbase + (unsigned)((pj * WX_XOPS + q) * 1024));
+        for (int u = 0; u < WX_NS; ++u) {
+            if (!set_on[u]) continue; // an inactive set's ring area is never read
+            const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot[u] * 16;
+#pragma unroll
+            for (int q = 0; q < WX_XOPS; ++q) {
+                const int g = g0 + q;
+                const char *src = ctb + (int64_t)g * row_bytes + voff;
+                if (dirty_lane[u] && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot[u] * d + (int64_t)g * 4) * 4;
+                glds16_asm(src, sbase + (unsigned)((u * WB_SG + pj * WX_XOPS + q) * 1024));
+            }
         }
-        glds16_asm(csrc + (int64_t)stage * (WB_SG * 16), sbase + (unsigned)(WB_SG * 1024 + pj * 1024));
+#pragma unroll
+        for (int q = 0; q < WX_COPS; ++q)
+            glds16_asm(csrc + (int64_t)q * 4 * cn_stride * 4 + (int64_t)stage * (WB_SG * 16), sbase + (unsigned)(WX_NS * WB_SG * 1024 + (pj * WX_COPS + q) * 1024));
     };
+    const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
     const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
     if (loader && do_load)
         for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i);
-    // the chain waves' new centroids: wave-uniform addresses -> scalar loads
     const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * WX_CPW : 0);
     const int jB = __builtin_amdgcn_readfirstlane(jA + (WX_CPW - 1));
     const bool chain = wave < WX_CW && jA < nb;
-    float sA = 0.0f, sB = 0.0f;
-    auto consume = [&](int stage) {
-        const float4 *xr = wb_lds + (stage % WX_R) * WX_STAGE_F4 + lane;
-        const float4 *ca = wb_lds + (stage % WX_R) * WX_STAGE_F4 + WB_SG * 64 + jA * WB_SG; // wave-uniform: broadcast reads
-        const float4 *cb = wb_lds + (stage % WX_R) * WX_STAGE_F4 + WB_SG * 64 + jB * WB_SG;
+    float sA[WX_NS], sB[WX_NS];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 xv[WB_SG / 2];
+    for (int u = 0; u < WX_NS; ++u) sA[u] = sB[u] = 0.0f;
+    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
+    auto quarter = [&](const float4 *xr, const float4 *ca, const float4 *cb, auto nsets_tag) {
+        constexpr int NSETS = decltype(nsets_tag)::value;
+        float4 xv[NSETS][4], c0[4], c1[4];
 #pragma unroll
-            for (int g = 0; g < WB_SG / 2; ++g) xv[g] = xr[(h * (WB_SG / 2) + g) * 64];
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int g = 0; g < WB_SG / 2; ++g) {
-                const float4 c0 = ca[h * (WB_SG / 2) + g];
-                const f2 xa = {xv[g].x, xv[g].y}, xb = {xv[g].z, xv[g].w};
-                const f2 a0 = {c0.x, c0.y}, a1 = {c0.z, c0.w};
+            for (int u = 0; u < NSETS; ++u) xv[u][g] = xr[(u * WB_SG + g) * 64];
+            c0[g] = ca[g];
+            if (WX_CPW == 2) c1[g] = cb[g];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f2 qa[NSETS], qb[NSETS], ra[NSETS], rb[NSETS];
+#pragma unroll
+            for (int u = 0; u < NSETS; ++u) {
+                const f2 xa = {xv[u][g].x, xv[u][g].y}, xb = {xv[u][g].z, xv[u][g].w};
+                const f2 a0 = {c0[g].x, c0[g].y}, a1 = {c0[g].z, c0[g].w};
                 const f2 da = xa - a0, db = xb - a1; // clustering.go:139 via :84
-                const f2 qa = da * da, qb = db * db; // :154 products, each rounded
+                qa[u] = da * da;                     // :154 products, each rounded
+                qb[u] = db * db;
                 if (WX_CPW == 2) {
-                    const float4 c1 = cb[h * (WB_SG / 2) + g];
-                    const f2 b0 = {c1.x, c1.y}, b1 = {c1.z, c1.w};
+                    const f2 b0 = {c1[g].x, c1[g].y}, b1 = {c1[g].z, c1[g].w};
                     const f2 ea = xa - b0, eb = xb - b1;
-                    const f2 ra = ea * ea, rb = eb * eb;
-                    sA = sA + qa.x; // :154 the running sums, each strictly in k order; the two chains alternate
-                    sB = sB + ra.x;
-                    sA = sA + qa.y;
-                    sB = sB + ra.y;
-                    sA = sA + qb.x;
-                    sB = sB + rb.x;
-                    sA = sA + qb.y;
-                    sB = sB + rb.y;
-                } else {
-                    sA = sA + qa.x;
-                    sA = sA + qa.y;
-                    sA = sA + qb.x;
-                    sA = sA + qb.y;
+                    ra[u] = ea * ea;
+                    rb[u] = eb * eb;
                 }
             }
+            // :154 the running sums, each strictly in k order; the independent sums alternate so that no add waits for the
+            // one just issued
+#pragma unroll
+            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qa[u].x; if (WX_CPW == 2) sB[u] = sB[u] + ra[u].x; }
+#pragma unroll
+            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qa[u].y; if (WX_CPW == 2) sB[u] = sB[u] + ra[u].y; }
+#pragma unroll
+            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qb[u].x; if (WX_CPW == 2) sB[u] = sB[u] + rb[u].x; }
+#pragma unroll
+            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qb[u].y; if (WX_CPW == 2) sB[u] = sB[u] + rb[u].y; }
+        }
+    };
+    auto consume = [&](int stage) {
+        const float4 *sb_ = wb_lds + (stage % WX_R) * WX_STAGE_F4;
+        const float4 *xr = sb_ + lane;
+        const float4 *ca = sb_ + WX_NS * WB_SG * 64 + jA * WB_SG; // wave-uniform: broadcast reads
+        const float4 *cb = sb_ + WX_NS * WB_SG * 64 + jB * WB_SG;
+#pragma unroll
+        for (int q = 0; q < WB_SG / 4; ++q) {
+            if (two) quarter(xr + q * 4 * 64, ca + q * 4, cb + q * 4, std::integral_constant<int, WX_NS>());
+            else quarter(xr + q * 4 * 64, ca + q * 4, cb + q * 4, std::integral_constant<int, 1>());
         }
     };
     for (int i = 0; i < nstage; ++i) {
         if (loader) {
             // stage i has landed once at most the WX_R-2 younger stages are outstanding (in the tail nothing new is issued:
-            // wait for everything, those stages have been in flight all along)
-            if (i + WX_R - 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * WX_OPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // wait for everything, those stages have been in flight all along).  A workgroup with one live set issues fewer
+            // pieces per stage, so its count is smaller.
+            if (i + WX_R - 2 < nstage) {
+                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_NS * WX_XOPS + WX_COPS)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_XOPS + WX_COPS)) : "memory");
+            } else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of stage i-1 have returned before its ring slot is refilled
         }
         __builtin_amdgcn_s_barrier();
         if (loader) {
             if (any_dirty && i >= 2) { // re-make the dirty columns from the stage that has just landed (rare)
-                const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + lane;
 #pragma unroll
-                for (int q = 0; q < WX_XOPS; ++q) {
-                    const int g = i * WB_SG + pj * WX_XOPS + q;
-                    if (dirty_lane && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot)) = xr[(pj * WX_XOPS + q) * 64];
+                for (int u = 0; u < WX_NS; ++u) {
+                    const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + u * WB_SG * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < WX_XOPS; ++q) {
+                        const int g = i * WB_SG + pj * WX_XOPS + q;
+                        if (dirty_lane[u] && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot[u])) = xr[(pj * WX_XOPS + q) * 64];
+                    }
                 }
             }
             if (i + WX_R - 1 < nstage && do_load) issue(i + WX_R - 1); // into the slot stage i-1 was read from: every chain wave is past this barrier
@@ -1892,23 +1972,31 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     for (int cc = 0; cc < WX_CPW; ++cc) {
         const int j = jA + cc;
         if (j >= nb) break;
-        const float s = cc ? sB : sA;
-        unsigned long long key = ~0ull;
-        if ((okmask >> j) & 1u) {
-            int sc = psc[0];
+        int sc = psc[0];
 #pragma unroll
-            for (int q = 1; q < WB_K; ++q)
-                if (j == q) sc = psc[q];
-            const float num = (float)((int64_t)sx * (int64_t)sc);
-            const float den = (float)(sx + sc);
-            const float val = (num / den) * s;
-            const int64_t c = n + t + j;
-            Dtri[rowoff[c] + x] = val;
-            if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+        for (int q = 1; q < WB_K; ++q)
+            if (j == q) sc = psc[q];
+        const int64_t c = n + t + j;
+        const int64_t ro = rowoff[c];
+        unsigned long long key = ~0ull, key2 = ~0ull;
+#pragma unroll
+        for (int u = 0; u < WX_NS; ++u) {
+            const float s = cc ? sB[u] : sA[u];
+            if ((okmask[u] >> j) & 1u) {
+                const float num = (float)((int64_t)sx[u] * (int64_t)sc);
+                const float den = (float)(sx[u] + sc);
+                const float val = (num / den) * s;
+                Dtri[ro + x[u]] = val;
+                if (val < ICL_MAXF) {
+                    const unsigned long long k = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x[u];
+                    key = k < key ? k : key;
+                    // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the
+                    // validation needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's
+                    // cache after a full commit
+                    if (survives[u]) key2 = k < key2 ? k : key2;
+                }
+            }
         }
-        // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the validation
-        // needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's cache after a full commit
-        unsigned long long key2 = survives ? key : ~0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_down(key, off, 64);
@@ -3153,7 +3241,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             const char *e = getenv("ICL_WX_DIAG");
             return e ? atoi(e) : 0;
         }();
-        const unsigned wx_blocks = (unsigned)(w->S / 64) + 2 + WB_R;
+        const unsigned wx_blocks = (unsigned)((w->S / 64 + WX_NS - 1) / WX_NS) + 2 + WB_R;
         static bool wx_attr = false;
         if (!wx_attr) {
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
