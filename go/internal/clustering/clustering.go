@@ -14,8 +14,9 @@ import "C"
 import (
 	"fmt"
 	"log"
-	"sync"
 	"unsafe"
+
+	"imageclust/internal/iclengine"
 )
 
 // Cluster mirrors clustering.go:11-15.
@@ -25,19 +26,10 @@ type Cluster struct {
 	Centroid []float32
 }
 
-var (
-	ctxOnce sync.Once
-	ctx     *C.icl_ctx
-	ctxErr  error
-)
-
+// engine: the context shared with internal/embeddings (one GPU context and workspace per process).
 func engine() (*C.icl_ctx, error) {
-	ctxOnce.Do(func() {
-		if rc := C.icl_create(0, &ctx); rc != C.ICL_OK {
-			ctxErr = fmt.Errorf("icl_create: %s", C.GoString(C.icl_last_error(nil)))
-		}
-	})
-	return ctx, ctxErr
+	p, err := iclengine.Ctx()
+	return (*C.icl_ctx)(p), err
 }
 
 // NewCluster: clustering.go:18-26 (plain Go, unchanged).
@@ -65,8 +57,10 @@ func MergeClusters(a, b Cluster) Cluster {
 	}
 	out := make([]float32, len(a.Centroid))
 	if len(out) > 0 {
-		C.icl_merge_centroid(e, (*C.float)(unsafe.Pointer(&a.Centroid[0])), C.int64_t(a.Size),
-			(*C.float)(unsafe.Pointer(&b.Centroid[0])), C.int64_t(b.Size), C.int32_t(len(out)), (*C.float)(unsafe.Pointer(&out[0])))
+		if rc := C.icl_merge_centroid(e, (*C.float)(unsafe.Pointer(&a.Centroid[0])), C.int64_t(a.Size),
+			(*C.float)(unsafe.Pointer(&b.Centroid[0])), C.int64_t(b.Size), C.int32_t(len(out)), (*C.float)(unsafe.Pointer(&out[0]))); rc != C.ICL_OK {
+			log.Panicf("icl_merge_centroid: %s", C.GoString(C.icl_last_error(e))) // never a silent zero centroid
+		}
 	}
 	return Cluster{Indices: append(append([]int{}, a.Indices...), b.Indices...), Size: a.Size + b.Size, Centroid: out}
 }
@@ -131,6 +125,63 @@ func FindClosestClusters(distanceMatrix [][]float32) (int, int) {
 		log.Panicf("icl_find_closest: %s", C.GoString(C.icl_last_error(e)))
 	}
 	return int(i), int(j)
+}
+
+// UpdateDistanceMatrix: clustering.go:76-96 -> icl_update_distance_matrix (rows/columns removedIdx1, removedIdx2 dropped
+// order-preserving, new last row/column from the centroids).  clusters is the list AFTER RemoveClusters + append (:240-241).
+func UpdateDistanceMatrix(distanceMatrix [][]float32, clusters []Cluster, newCluster Cluster, removedIdx1, removedIdx2 int) [][]float32 {
+	n := len(distanceMatrix)
+	e, err := engine()
+	if err != nil {
+		log.Panic(err)
+	}
+	flatD := make([]float32, n*n)
+	for i, row := range distanceMatrix {
+		copy(flatD[i*n:(i+1)*n], row)
+	}
+	flatC, sizes, d := flatten(clusters)
+	m := n - 1
+	out := make([]float32, m*m)
+	var cptr *C.float
+	if d > 0 {
+		cptr = (*C.float)(unsafe.Pointer(&flatC[0]))
+	}
+	if rc := C.icl_update_distance_matrix(e, (*C.float)(unsafe.Pointer(&flatD[0])), C.int64_t(n), C.int64_t(n), cptr,
+		(*C.int32_t)(unsafe.Pointer(&sizes[0])), C.int32_t(d), C.int64_t(removedIdx1), C.int64_t(removedIdx2),
+		(*C.float)(unsafe.Pointer(&out[0])), C.int64_t(m)); rc != C.ICL_OK {
+		log.Panicf("icl_update_distance_matrix: %s", C.GoString(C.icl_last_error(e)))
+	}
+	res := make([][]float32, m)
+	for i := range res {
+		res[i] = out[i*m : (i+1)*m : (i+1)*m]
+	}
+	return res
+}
+
+// RemoveRowsAndColumns: clustering.go:100-116 (plain Go, unchanged).
+func RemoveRowsAndColumns(matrix [][]float32, i, j int) [][]float32 {
+	if i > j {
+		i, j = j, i
+	}
+	for idx := range matrix {
+		matrix[idx] = append(matrix[idx][:j], matrix[idx][j+1:]...)
+		matrix[idx] = append(matrix[idx][:i], matrix[idx][i+1:]...)
+	}
+	matrix = append(matrix[:j], matrix[j+1:]...)
+	matrix = append(matrix[:i], matrix[i+1:]...)
+	return matrix
+}
+
+// DotFloat32: clustering.go:148-157 (plain Go, unchanged: in-order fp32 sum, panics on length mismatch).
+func DotFloat32(a, b []float32) float32 {
+	if len(a) != len(b) {
+		panic("Vectors must be the same length")
+	}
+	var sum float32
+	for i := range a {
+		sum += a[i] * b[i]
+	}
+	return sum
 }
 
 // WardDistance: clustering.go:136-145 (a 2x2 call of the exact distance tile).

@@ -13,20 +13,43 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"sync"
 	"unsafe"
+
+	"imageclust/internal/iclengine"
 )
 
-// Net stands in for gocv.Net: a GPU context holding ResNet50-v1 weights in HBM.
+// Net stands in for gocv.Net: the process-wide GPU context (shared with internal/clustering through iclengine) holding
+// ResNet50-v1 weights in HBM.  Close releases nothing: the context lives as long as the process, like the reference's model
+// which workflow.go:49-50 reloads per request only because nothing caches it.
 type Net struct{ ctx *C.icl_ctx }
 
 func (n Net) Empty() bool { return n.ctx == nil }
 func (n *Net) Close() error {
-	if n.ctx != nil {
-		C.icl_destroy(n.ctx)
-		n.ctx = nil
-	}
+	n.ctx = nil
 	return nil
+}
+
+// Mat stands in for gocv.Mat (embeddings.go:46): the 1x3x224x224 fp32 NCHW blob PreprocessImage returns.
+type Mat struct{ Data []float32 }
+
+func (m Mat) Size() []int  { return []int{1, 3, 224, 224} }
+func (m Mat) Empty() bool  { return len(m.Data) == 0 }
+func (m *Mat) Close() error { m.Data = nil; return nil }
+
+// PreprocessImage: embeddings.go:46-116 -> icl_preprocess_file (IMRead incl. EXIF orientation, cv::resize 224x224
+// INTER_LINEAR, BGR->RGB, x/255, NCHW).  The blob is Go-owned.
+func PreprocessImage(imagePath string) (Mat, error) {
+	out := make([]float32, 3*224*224)
+	p := C.CString(imagePath)
+	defer C.free(unsafe.Pointer(p))
+	runtime.LockOSThread() // icl_last_error(NULL) is thread-local: keep the call and the read on one OS thread
+	defer runtime.UnlockOSThread()
+	if rc := C.icl_preprocess_file(p, (*C.float)(unsafe.Pointer(&out[0]))); rc != C.ICL_OK {
+		return Mat{}, fmt.Errorf("%s", C.GoString(C.icl_last_error(nil)))
+	}
+	return Mat{Data: out}, nil
 }
 
 // AppContext mirrors embeddings.go:17-25.
@@ -42,22 +65,23 @@ type AppContext struct {
 
 // LoadPretrainedModelONNX: embeddings.go:28-43.
 func LoadPretrainedModelONNX(modelPath string) (Net, error) {
-	var ctx *C.icl_ctx
-	if rc := C.icl_create(0, &ctx); rc != C.ICL_OK {
-		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%s)", modelPath, C.GoString(C.icl_last_error(nil)))
+	raw, err := iclengine.Ctx() // one context per process, shared with internal/clustering
+	if err != nil {
+		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%v)", modelPath, err)
 	}
+	ctx := (*C.icl_ctx)(raw)
 	p := C.CString(modelPath)
 	defer C.free(unsafe.Pointer(p))
 	if rc := C.icl_model_load_onnx(ctx, p); rc != C.ICL_OK {
-		msg := C.GoString(C.icl_last_error(ctx))
-		C.icl_destroy(ctx)
-		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%s)", modelPath, msg)
+		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%s)", modelPath, C.GoString(C.icl_last_error(ctx)))
 	}
 	return Net{ctx: ctx}, nil
 }
 
 // GetImageEmbedding: embeddings.go:119-163.  The returned slice is Go-owned (the reference's slice aliases a freed
-// cv::Mat: embeddings.go:145-152); the engine is thread-safe, NetMutex is kept only for field compatibility.
+// cv::Mat: embeddings.go:145-152).  workflow.go:156-175 calls this from one goroutine per image: icl_embed_file decodes and
+// resizes on the calling thread and COALESCES the concurrent callers into batched forward passes (icl_set_file_options),
+// so NetMutex is kept only for field compatibility and is not taken.
 func GetImageEmbedding(appCtx *AppContext, imagePath string) ([]float32, error) {
 	if appCtx.Net.Empty() {
 		return nil, fmt.Errorf("failed to generate embedding for image: %s", imagePath)

@@ -1,0 +1,46 @@
+// Package iclengine owns the ONE libimageclust_hip.so context the drop-in packages share (internal/embeddings holds the
+// model in it, internal/clustering clusters on it): a process that loads both packages creates one GPU context and one
+// set of workspaces, not two.  NOT COMPILED in the authoring container (no Go toolchain): logic-free glue.
+package iclengine
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../imageclust_amd -limageclust_hip
+#include "imageclust.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"runtime"
+	"sync"
+	"unsafe"
+)
+
+var (
+	once sync.Once
+	ctx  *C.icl_ctx
+	err  error
+)
+
+// Ctx returns the shared context as an unsafe.Pointer (cgo types are package-local: each caller casts it back to its
+// own *C.icl_ctx), creating it on first use.  ICL_DEVICE in the environment selects the GPU (icl_create's device ordinal 0 otherwise).
+func Ctx() (unsafe.Pointer, error) {
+	once.Do(func() {
+		// icl_last_error(NULL) reads a thread-local string: keep the failing call and the read on one OS thread
+		runtime.LockOSThread()
+		defer runtime.UnlockOSThread()
+		if rc := C.icl_create(0, &ctx); rc != C.ICL_OK {
+			err = fmt.Errorf("icl_create: %s", C.GoString(C.icl_last_error(nil)))
+		}
+	})
+	return unsafe.Pointer(ctx), err
+}
+
+// LastError returns the message of the last failed call on the context (stored in the context, not in TLS).
+func LastError() string {
+	if ctx == nil {
+		return "no context"
+	}
+	return C.GoString(C.icl_last_error(ctx))
+}

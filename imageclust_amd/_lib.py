@@ -45,7 +45,11 @@ SYMBOLS = [
     ("icl_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_embed_u8_dev", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_embed_file", _int, [_vp, C.c_char_p, _int, _vp]),
+    ("icl_set_file_options", _int, [_vp, _int, _int, _int]),
+    ("icl_file_batch_stats", _int, [_vp, _pi64, _pi64]),
     ("icl_preprocess_u8", _int, [_vp, _vp]),
+    ("icl_preprocess_file", _int, [C.c_char_p, _vp]),
+    ("icl_resize_u8", _int, [_vp, _i32, _i32, _vp, _i32, _i32]),
     ("icl_decode_image_file", _int, [C.c_char_p, _vp, _i64, _pi32, _pi32]),
     ("icl_load_image_224", _int, [C.c_char_p, _vp]),
     ("icl_set_batch", _int, [_vp, _int]),
@@ -54,6 +58,7 @@ SYMBOLS = [
     ("icl_ward_distance_matrix", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
     ("icl_ward_distance_matrix_dev", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
     ("icl_merge_centroid", _int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp]),
+    ("icl_update_distance_matrix", _int, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i64, _vp, _i64]),
     ("icl_find_closest", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
     ("icl_find_closest_dev", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
     ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
@@ -222,6 +227,27 @@ class Context:
         check(self.h, self.L.icl_embed_file(self.h, os.fsencode(path), head, out.ctypes.data))
         return out
 
+    def set_file_options(self, prec=PREC_FP32, window_us=2000, max_batch=256):
+        """How icl_embed_file coalesces concurrent callers (workflow.go:156-175: one goroutine per image)."""
+        check(self.h, self.L.icl_set_file_options(self.h, prec, window_us, max_batch))
+
+    def file_batch_stats(self):
+        b, i = _i64(), _i64()
+        check(self.h, self.L.icl_file_batch_stats(self.h, C.byref(b), C.byref(i)))
+        return {"batches": b.value, "images": i.value}
+
+    def update_distance_matrix(self, D, centroids, sizes, r1, r2):
+        """UpdateDistanceMatrix (clustering.go:76-96): D n x n before the merge; centroids / sizes of the n-1 clusters after
+        RemoveClusters + append (new cluster last) -> (n-1) x (n-1)."""
+        D = np.ascontiguousarray(D, np.float32)
+        Cm = np.ascontiguousarray(centroids, np.float32)
+        sz = np.ascontiguousarray(sizes, np.int32)
+        n = D.shape[0]
+        out = np.zeros((n - 1, n - 1), np.float32)
+        check(self.h, self.L.icl_update_distance_matrix(self.h, D.ctypes.data, n, D.shape[1], Cm.ctypes.data, sz.ctypes.data,
+                                                        Cm.shape[1] if Cm.ndim == 2 else 0, int(r1), int(r2), out.ctypes.data, n - 1))
+        return out
+
     def conv2d_fused(self, x_nhwc, w_oihw, scale, shift, stride=1, pad=0, residual=None, relu=True, prec=PREC_FP32):
         x = np.ascontiguousarray(x_nhwc, np.float32)
         w = np.ascontiguousarray(w_oihw, np.float32)
@@ -333,6 +359,26 @@ def decode_image_file(path):
     rc = L.icl_decode_image_file(os.fsencode(path), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h))
     if rc:
         raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
+    return out
+
+
+def preprocess_file(path):
+    """PreprocessImage(imagePath) (embeddings.go:46-116) -> (1, 3, 224, 224) fp32 NCHW."""
+    out = np.empty((1, 3, 224, 224), np.float32)
+    rc = load().icl_preprocess_file(os.fsencode(path), out.ctypes.data)
+    if rc:
+        raise ICLError(rc, (load().icl_last_error(None) or b"").decode())
+    return out
+
+
+def resize_u8(img, dw, dh):
+    """cv::resize(img, (dw, dh), INTER_LINEAR) on an h x w x 3 u8 image (embeddings.go:69)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    out = np.empty((dh, dw, 3), np.uint8)
+    rc = load().icl_resize_u8(img.ctypes.data, w, h, out.ctypes.data, dw, dh)
+    if rc:
+        raise ICLError(rc, "icl_resize_u8")
     return out
 
 

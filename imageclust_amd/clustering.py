@@ -79,17 +79,25 @@ def WardDistance(a: Cluster, b: Cluster, ctx: Optional[_lib.Context] = None) -> 
 
 def UpdateDistanceMatrix(distanceMatrix: np.ndarray, clusters: List[Cluster], newCluster: Cluster, removedIdx1: int,
                          removedIdx2: int, ctx: Optional[_lib.Context] = None) -> np.ndarray:
-    """clustering.go:76-96: drop two rows/columns, append the new cluster's row/column computed from centroids.
-    `clusters` is the list AFTER removal and append (newCluster last), as at clustering.go:244."""
+    """clustering.go:76-96: drop two rows/columns, append the new cluster's row/column computed from centroids
+    (icl_update_distance_matrix).  `clusters` is the list AFTER removal and append (newCluster last), as at
+    clustering.go:244; newCluster is accepted for signature parity and must be clusters[-1]."""
     ctx = ctx or default_context()
-    D = RemoveRowsAndColumns(np.asarray(distanceMatrix, np.float32), removedIdx1, removedIdx2)
-    n = len(clusters)
-    full = ComputeInitialDistanceMatrix(clusters, ctx)
-    out = np.zeros((n, n), np.float32)
-    out[: n - 1, : n - 1] = D
-    out[n - 1, :] = full[n - 1, :]
-    out[:, n - 1] = full[:, n - 1]
-    return out
+    C = np.stack([np.asarray(c.Centroid, np.float32) for c in clusters])
+    sizes = np.array([c.Size for c in clusters], np.int32)
+    return ctx.update_distance_matrix(np.asarray(distanceMatrix, np.float32), C, sizes, removedIdx1, removedIdx2)
+
+
+def DotFloat32(a, b) -> np.float32:
+    """clustering.go:148-157: in-order fp32 dot product, product rounded then sum rounded; panics on length mismatch."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    if a.shape != b.shape:
+        raise ValueError("vectors must be the same length")  # clustering.go:150 panics
+    s = np.float32(0)
+    for p in (a * b).astype(np.float32):
+        s = np.float32(s + p)
+    return s
 
 
 def FindClosestClusters(distanceMatrix, ctx: Optional[_lib.Context] = None) -> Tuple[int, int]:

@@ -47,6 +47,7 @@ struct icl_ctx {
     // subsystems
     icl_model *model = nullptr;
     icl_ward_ws *ward = nullptr;
+    void *file_batcher = nullptr; // icl_embed_file's coalescing queue (resnet.hip)
     std::vector<int32_t> last_merges; // pairs
     std::vector<float> last_merge_vals; // Ward distance of each merged pair
 };
@@ -95,6 +96,7 @@ void icl_prof_collect(icl_ctx *ctx); // resolves pending events (requires the st
 // subsystem teardown hooks
 void icl_model_free(icl_ctx *ctx);
 void icl_ward_free(icl_ctx *ctx);
+void icl_file_batcher_free(icl_ctx *ctx);
 
 static inline int64_t icl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

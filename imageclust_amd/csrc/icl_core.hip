@@ -71,6 +71,7 @@ extern "C" void icl_destroy(icl_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     icl_model_free(ctx);
     icl_ward_free(ctx);
+    icl_file_batcher_free(ctx);
     for (auto &p : ctx->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);

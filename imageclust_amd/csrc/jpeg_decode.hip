@@ -218,14 +218,17 @@ void idct_islow(const int *coef, uint8_t *out, int stride)
 } // namespace
 
 #define ICL_JPEG_MAX_PIXELS (64LL << 20)
-static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H);
+static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H, int &orient);
 
 // Decodes a JPEG file held in memory to interleaved RGB.  rgb is resized to w*h*3.  No C++ exception may cross the C ABI
 // (cgo / ctypes would std::terminate the host process): allocation failures become status codes here.
-int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H)
+// orient receives the EXIF orientation tag (1..8; 1 when absent): cv::imread applies it after decoding (embeddings.go:50
+// passes IMReadColor without IMREAD_IGNORE_ORIENTATION), the caller does the same (resnet.hip apply_exif_orientation).
+int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H, int &orient)
 {
+    orient = 1;
     try {
-        return jpeg_decode_impl(ctx, data, len, path, rgb, W, H);
+        return jpeg_decode_impl(ctx, data, len, path, rgb, W, H, orient);
     } catch (const std::bad_alloc &) {
         return icl_fail(ctx, ICL_ERR_NOMEM, "failed to read image: %s. Out of host memory while decoding", path);
     } catch (...) {
@@ -233,7 +236,35 @@ int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *p
     }
 }
 
-static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H)
+// EXIF (APP1 "Exif\0\0" + TIFF header): orientation tag 0x0112 of IFD0, 1..8; anything malformed reads as 1.
+static int exif_orientation(const uint8_t *s, size_t sl)
+{
+    if (sl < 14 || memcmp(s, "Exif\0\0", 6) != 0) return 1;
+    const uint8_t *t = s + 6;
+    const size_t tl = sl - 6;
+    const bool le = t[0] == 'I' && t[1] == 'I', be = t[0] == 'M' && t[1] == 'M';
+    if (!le && !be) return 1;
+    auto u16 = [&](size_t o) -> unsigned { return le ? (unsigned)(t[o] | (t[o + 1] << 8)) : (unsigned)((t[o] << 8) | t[o + 1]); };
+    auto u32 = [&](size_t o) -> unsigned {
+        return le ? (unsigned)t[o] | ((unsigned)t[o + 1] << 8) | ((unsigned)t[o + 2] << 16) | ((unsigned)t[o + 3] << 24)
+                  : ((unsigned)t[o] << 24) | ((unsigned)t[o + 1] << 16) | ((unsigned)t[o + 2] << 8) | (unsigned)t[o + 3];
+    };
+    if (u16(2) != 42) return 1;
+    const size_t ifd = u32(4);
+    if (ifd + 2 > tl) return 1;
+    const unsigned nent = u16(ifd);
+    for (unsigned e = 0; e < nent; ++e) {
+        const size_t o = ifd + 2 + (size_t)e * 12;
+        if (o + 12 > tl) return 1;
+        if (u16(o) == 0x0112) {
+            const unsigned v = u16(o + 8); // type SHORT, count 1: the value sits in the first two bytes of the value field
+            return (u16(o + 2) == 3 && v >= 1 && v <= 8) ? (int)v : 1;
+        }
+    }
+    return 1;
+}
+
+static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H, int &orient)
 {
     auto fail = [&](int code, const char *what) { return icl_fail(ctx, code, "failed to read image: %s. %s", path, what); };
     if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(ICL_ERR_IO, "Not a JPEG stream");
@@ -335,6 +366,8 @@ static int jpeg_decode_impl(icl_ctx *ctx, const uint8_t *data, size_t len, const
             return fail(ICL_ERR_UNSUPPORTED, "Lossless / hierarchical / arithmetic-coded JPEG is not decoded by this build");
         } else if (m == 0xDD) {
             if (sl >= 2) restart = (s[0] << 8) | s[1];
+        } else if (m == 0xE1) {
+            if (orient == 1) orient = exif_orientation(s, sl); // the first APP1/Exif segment decides, as in OpenCV's ExifReader
         } else if (m == 0xEE) {
             if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
         } else if (m == 0xDA) { // SOS: one scan (a baseline file has one or ncomp of them, a progressive file many)

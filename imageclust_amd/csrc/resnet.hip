@@ -18,7 +18,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #define ICL_MAX_LANES 4 /* forward passes in flight (ICL_EMBED_STREAMS) */
@@ -1183,6 +1186,19 @@ extern "C" int icl_preprocess_u8(const uint8_t *hwc, float *nchw)
 static void resize_bilinear_u8(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
 {
     const int cn = 3;
+    if (sw == 2 * dw && sh == 2 * dh) {
+        // cv::resize switches INTER_LINEAR to INTER_AREA for an exact 2x2 decimation ("if (interpolation == INTER_LINEAR &&
+        // is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA"); ResizeAreaFast on 8-bit data is the
+        // rounded mean of the 2x2 block: (a + b + c + d + 2) >> 2
+        for (int y = 0; y < dh; ++y) {
+            const uint8_t *r0 = src + (size_t)(2 * y) * sw * cn, *r1 = r0 + (size_t)sw * cn;
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < cn; ++c)
+                    dst[((size_t)y * dw + x) * cn + c] =
+                        (uint8_t)((r0[(2 * x) * cn + c] + r0[(2 * x + 1) * cn + c] + r1[(2 * x) * cn + c] + r1[(2 * x + 1) * cn + c] + 2) >> 2);
+        }
+        return;
+    }
     std::vector<int> xofs((size_t)dw), yofs((size_t)dh);
     std::vector<short> xa((size_t)dw * 2), ya((size_t)dh * 2);
     auto coeffs = [](int dn, int sn, std::vector<int> &ofs, std::vector<short> &al) {
@@ -1248,7 +1264,35 @@ static int read_ppm(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, i
     return ICL_OK;
 }
 
-int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H); // jpeg_decode.hip
+int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H, int &orient); // jpeg_decode.hip
+
+// cv::imread rotates / mirrors the decoded pixels by the file's EXIF orientation (OpenCV ExifTransform): 2 mirror
+// horizontally, 3 rotate 180, 4 mirror vertically, 5 transpose, 6 rotate 90 clockwise, 7 transverse, 8 rotate 90 counter-clockwise.
+static void apply_exif_orientation(std::vector<uint8_t> &rgb, int &w, int &h, int orient)
+{
+    if (orient <= 1 || orient > 8) return;
+    const int sw = w, sh = h;
+    const bool swap = orient >= 5;
+    const int dw = swap ? sh : sw, dh = swap ? sw : sh;
+    std::vector<uint8_t> out((size_t)dw * dh * 3);
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            int sx, sy; // source pixel of destination (x, y)
+            switch (orient) {
+            case 2: sx = sw - 1 - x; sy = y; break;
+            case 3: sx = sw - 1 - x; sy = sh - 1 - y; break;
+            case 4: sx = x; sy = sh - 1 - y; break;
+            case 5: sx = y; sy = x; break;
+            case 6: sx = y; sy = sh - 1 - x; break;
+            case 7: sx = sw - 1 - y; sy = sh - 1 - x; break;
+            default: sx = sw - 1 - y; sy = x; break; // 8
+            }
+            memcpy(&out[((size_t)y * dw + x) * 3], &rgb[((size_t)sy * sw + sx) * 3], 3);
+        }
+    rgb.swap(out);
+    w = dw;
+    h = dh;
+}
 
 // IMRead(IMReadColor) of embeddings.go:50 for the two formats this build decodes.
 static int read_image(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
@@ -1265,43 +1309,197 @@ static int read_image(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb,
         const bool ok = sz > 0 && fread(file.data(), 1, file.size(), f) == file.size();
         fclose(f);
         if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path);
-        return icl_jpeg_decode(ctx, file.data(), file.size(), path, rgb, w, h);
+        int orient = 1;
+        ICL_TRY(icl_jpeg_decode(ctx, file.data(), file.size(), path, rgb, w, h, orient));
+        apply_exif_orientation(rgb, w, h, orient);
+        return ICL_OK;
     }
     fclose(f);
     return read_ppm(ctx, path, rgb, w, h);
 }
 
+// No C++ exception may cross the C ABI (cgo / ctypes would terminate the host process): the ingest entry points allocate
+// buffers whose sizes come from files.
+template <typename F>
+static int no_throw(icl_ctx *ctx, const char *what, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return icl_fail(ctx, ICL_ERR_NOMEM, "%s: out of host memory", what);
+    } catch (...) {
+        return icl_fail(ctx, ICL_ERR_IO, "%s: unexpected failure", what);
+    }
+}
+
 extern "C" int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h)
 {
     if (!path || !w || !h) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: bad argument");
-    std::vector<uint8_t> px;
-    int iw = 0, ih = 0;
-    ICL_TRY(read_image(nullptr, path, px, iw, ih));
-    *w = iw;
-    *h = ih;
-    if (rgb) {
-        if (cap_bytes < (int64_t)px.size()) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: buffer too small");
-        memcpy(rgb, px.data(), px.size());
-    }
-    return ICL_OK;
+    return no_throw(nullptr, "icl_decode_image_file", [&]() -> int {
+        std::vector<uint8_t> px;
+        int iw = 0, ih = 0;
+        ICL_TRY(read_image(nullptr, path, px, iw, ih));
+        *w = iw;
+        *h = ih;
+        if (rgb) {
+            if (cap_bytes < (int64_t)px.size()) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: buffer too small");
+            memcpy(rgb, px.data(), px.size());
+        }
+        return ICL_OK;
+    });
 }
 
 extern "C" int icl_load_image_224(const char *path, uint8_t *out)
 {
     if (!path || !out) return icl_fail(nullptr, ICL_ERR_ARG, "icl_load_image_224: bad argument");
-    std::vector<uint8_t> px;
-    int w = 0, h = 0;
-    ICL_TRY(read_image(nullptr, path, px, w, h));
-    resize_bilinear_u8(px.data(), w, h, out, ICL_IMG_W, ICL_IMG_H);
+    return no_throw(nullptr, "icl_load_image_224", [&]() -> int {
+        std::vector<uint8_t> px;
+        int w = 0, h = 0;
+        ICL_TRY(read_image(nullptr, path, px, w, h));
+        resize_bilinear_u8(px.data(), w, h, out, ICL_IMG_W, ICL_IMG_H);
+        return ICL_OK;
+    });
+}
+
+// cv::resize on an arbitrary u8 RGB image (the resize step of PreprocessImage alone; tests pin it to hand-derived vectors)
+extern "C" int icl_resize_u8(const uint8_t *src, int32_t sw, int32_t sh, uint8_t *dst, int32_t dw, int32_t dh)
+{
+    if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return icl_fail(nullptr, ICL_ERR_ARG, "icl_resize_u8: bad argument");
+    return no_throw(nullptr, "icl_resize_u8", [&]() -> int {
+        resize_bilinear_u8(src, sw, sh, dst, dw, dh);
+        return ICL_OK;
+    });
+}
+
+// PreprocessImage(imagePath) (embeddings.go:46-116): file -> the 1x3x224x224 fp32 NCHW blob.
+extern "C" int icl_preprocess_file(const char *path, float *nchw)
+{
+    if (!path || !nchw) return icl_fail(nullptr, ICL_ERR_ARG, "icl_preprocess_file: bad argument");
+    return no_throw(nullptr, "icl_preprocess_file", [&]() -> int {
+        std::vector<uint8_t> px, img((size_t)ICL_IMG_BYTES);
+        int w = 0, h = 0;
+        ICL_TRY(read_image(nullptr, path, px, w, h));
+        resize_bilinear_u8(px.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
+        return icl_preprocess_u8(img.data(), nchw);
+    });
+}
+
+// ---- GetImageEmbedding(path) from N goroutines (workflow.go:156-175) -------------------------------------------------
+// The reference serialises its batch-1 forward passes behind NetMutex (embeddings.go:133).  Here concurrent callers are
+// COALESCED: every caller decodes and resizes its own file in parallel, then joins a per-context queue; the first one
+// to arrive becomes the leader, waits a short window (or until a full batch has gathered), runs ONE forward pass over
+// everything queued and hands each caller its row.  fp32 rows do not depend on what else is in the batch (every output
+// pixel is its own in-order sum), so results equal the one-at-a-time path bit for bit.
+struct icl_file_req {
+    const uint8_t *img;
+    float *out;
+    int head;
+    int rc = ICL_OK;
+    bool done = false;
+    std::string err;
+};
+struct icl_file_batcher {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<icl_file_req *> pending;
+    bool leader = false;
+    int prec = ICL_PREC_FP32;
+    int window_us = 2000;
+    int max_batch = 256;
+    int64_t batches = 0, images = 0; // statistics (icl_file_batch_stats)
+};
+static icl_file_batcher *file_batcher(icl_ctx *ctx)
+{
+    static std::mutex gm;
+    std::lock_guard<std::mutex> lk(gm);
+    if (!ctx->file_batcher) ctx->file_batcher = new icl_file_batcher();
+    return (icl_file_batcher *)ctx->file_batcher;
+}
+void icl_file_batcher_free(icl_ctx *ctx)
+{
+    delete (icl_file_batcher *)ctx->file_batcher;
+    ctx->file_batcher = nullptr;
+}
+
+extern "C" int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch)
+{
+    if (!ctx || (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) || window_us < 0 || max_batch < 1 || max_batch > 4096)
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_set_file_options: bad argument");
+    icl_file_batcher *b = file_batcher(ctx);
+    std::lock_guard<std::mutex> lk(b->m);
+    b->prec = prec;
+    b->window_us = window_us;
+    b->max_batch = max_batch;
+    return ICL_OK;
+}
+
+extern "C" int icl_file_batch_stats(icl_ctx *ctx, int64_t *batches, int64_t *images)
+{
+    if (!ctx) return ICL_ERR_ARG;
+    icl_file_batcher *b = file_batcher(ctx);
+    std::lock_guard<std::mutex> lk(b->m);
+    if (batches) *batches = b->batches;
+    if (images) *images = b->images;
     return ICL_OK;
 }
 
 extern "C" int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out)
 {
     if (!ctx || !path || !out) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_file: bad argument");
-    std::vector<uint8_t> rgb, img((size_t)ICL_IMG_BYTES);
-    int w = 0, h = 0;
-    ICL_TRY(read_image(ctx, path, rgb, w, h));
-    resize_bilinear_u8(rgb.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
-    return icl_embed_u8(ctx, img.data(), 1, head, ICL_PREC_FP32, out);
+    if (head != ICL_HEAD_POOLED && head != ICL_HEAD_DENSE0) return icl_fail(ctx, ICL_ERR_ARG, "head must be 2048 or 1000");
+    return no_throw(ctx, "icl_embed_file", [&]() -> int {
+        std::vector<uint8_t> rgb, img((size_t)ICL_IMG_BYTES);
+        int w = 0, h = 0;
+        ICL_TRY(read_image(ctx, path, rgb, w, h)); // decode + resize run on the caller's thread, in parallel with other callers
+        resize_bilinear_u8(rgb.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
+        icl_file_batcher *b = file_batcher(ctx);
+        icl_file_req me;
+        me.img = img.data();
+        me.out = out;
+        me.head = head;
+        std::unique_lock<std::mutex> lk(b->m);
+        b->pending.push_back(&me);
+        if ((int)b->pending.size() >= b->max_batch) b->cv.notify_all(); // a waiting leader need not sit out its window
+        while (!me.done) {
+            if (b->leader) { // someone else is collecting or running a batch: wait for my row (or for the leadership)
+                b->cv.wait(lk);
+                continue;
+            }
+            b->leader = true;
+            if (b->window_us > 0 && (int)b->pending.size() < b->max_batch)
+                b->cv.wait_for(lk, std::chrono::microseconds(b->window_us), [&] { return (int)b->pending.size() >= b->max_batch; });
+            std::vector<icl_file_req *> take;
+            take.swap(b->pending);
+            if ((int)take.size() > b->max_batch) {
+                b->pending.assign(take.begin() + b->max_batch, take.end());
+                take.resize((size_t)b->max_batch);
+            }
+            const int prec = b->prec;
+            lk.unlock();
+            for (int hd : {ICL_HEAD_POOLED, ICL_HEAD_DENSE0}) { // one forward pass per requested head
+                std::vector<icl_file_req *> grp;
+                for (icl_file_req *r : take)
+                    if (r->head == hd) grp.push_back(r);
+                if (grp.empty()) continue;
+                std::vector<uint8_t> slab(grp.size() * (size_t)ICL_IMG_BYTES);
+                std::vector<float> res(grp.size() * (size_t)hd);
+                for (size_t i = 0; i < grp.size(); ++i) memcpy(&slab[i * (size_t)ICL_IMG_BYTES], grp[i]->img, (size_t)ICL_IMG_BYTES);
+                const int rc = icl_embed_u8(ctx, slab.data(), (int64_t)grp.size(), hd, prec, res.data());
+                const std::string err = rc ? ctx->err : std::string();
+                for (size_t i = 0; i < grp.size(); ++i) {
+                    grp[i]->rc = rc;
+                    grp[i]->err = err;
+                    if (rc == ICL_OK) memcpy(grp[i]->out, &res[i * (size_t)hd], (size_t)hd * 4);
+                }
+            }
+            lk.lock();
+            b->batches += 1;
+            b->images += (int64_t)take.size();
+            for (icl_file_req *r : take) r->done = true;
+            b->leader = false;
+            b->cv.notify_all(); // followers pick up their rows; one of the still-pending callers becomes the next leader
+        }
+        if (me.rc != ICL_OK) return icl_fail(ctx, me.rc, "%s", me.err.c_str());
+        return ICL_OK;
+    });
 }

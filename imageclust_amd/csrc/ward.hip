@@ -3467,6 +3467,81 @@ extern "C" int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, con
     return ICL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// UpdateDistanceMatrix (clustering.go:76-96) + RemoveRowsAndColumns (:100-116) as a stand-alone entry point: the merge
+// loop above never materialises the reference's compacted matrix, this does -- for callers that drive the reference's
+// loop themselves (clustering.go:237-244) and for the step-by-step replay test.
+//   D      n x n (leading dimension ld): the matrix BEFORE the merge
+//   r1, r2 positions of the two merged clusters (any order, r1 != r2)
+//   C      (n-1) x d centroids of the cluster list AFTER RemoveClusters + append (:240-241): the new cluster is last
+//   sizes  their sizes
+//   Dout   (n-1) x (n-1) (leading dimension ldout): rows/columns r1, r2 removed order-preserving, then the new last
+//          row/column = WardDistance(clusters[i], newCluster) from the centroids (NOT Lance-Williams), diagonal 0
+// ------------------------------------------------------------------------------------------------------------
+__global__ void udm_compact_kernel(const float *__restrict__ D, int64_t n, int64_t ld, int64_t lo, int64_t hi, float *__restrict__ out, int64_t ldo)
+{
+    const int64_t m = n - 2; // surviving rows / columns
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * m) return;
+    const int64_t i = idx / m, j = idx % m;
+    const int64_t si = i + (i >= lo) + (i + (i >= lo) >= hi), sj = j + (j >= lo) + (j + (j >= lo) >= hi);
+    out[i * ldo + j] = D[si * ld + sj];
+}
+
+__global__ void udm_newrow_kernel(const float *__restrict__ C, const int32_t *__restrict__ sizes, int64_t m1, int d, float *__restrict__ out, int64_t ldo)
+{
+    // one thread per surviving cluster i < m1-1: WardDistance(clusters[i], new) with the in-order, unfused fp32 sum (:136-157)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t last = m1 - 1;
+    if (i > last) return;
+    if (i == last) {
+        out[last * ldo + last] = 0.0f; // :87
+        return;
+    }
+    const float *a = C + i * d, *b = C + last * d;
+    float s = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const float df = a[k] - b[k];
+        const float p = df * df;
+        s = s + p;
+    }
+    const float num = (float)((int64_t)sizes[i] * (int64_t)sizes[last]);
+    const float den = (float)(sizes[i] + sizes[last]);
+    const float v = (num / den) * s;
+    out[i * ldo + last] = v; // :90-92
+    out[last * ldo + i] = v; // :93
+}
+
+extern "C" int icl_update_distance_matrix(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, const float *C, const int32_t *sizes, int32_t d,
+                                          int64_t r1, int64_t r2, float *Dout, int64_t ldout)
+{
+    if (!ctx || n < 2 || ld < n || ldout < n - 1 || d < 0 || !D || !Dout || !sizes || (d && !C) || r1 < 0 || r2 < 0 || r1 >= n || r2 >= n || r1 == r2)
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_update_distance_matrix: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    const int64_t lo = std::min(r1, r2), hi = std::max(r1, r2), m1 = n - 1;
+    struct dev_guard {
+        void *p = nullptr;
+        ~dev_guard() { if (p) (void)hipFree(p); }
+    } gD, gC, gS, gO;
+    ICL_HIP(ctx, hipMalloc(&gD.p, (size_t)(n * ld) * 4));
+    ICL_HIP(ctx, hipMalloc(&gC.p, (size_t)std::max<int64_t>(m1 * d, 1) * 4));
+    ICL_HIP(ctx, hipMalloc(&gS.p, (size_t)m1 * 4));
+    ICL_HIP(ctx, hipMalloc(&gO.p, (size_t)(m1 * m1) * 4));
+    ICL_HIP(ctx, hipMemcpyAsync(gD.p, D, (size_t)(n * ld) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (d) ICL_HIP(ctx, hipMemcpyAsync(gC.p, C, (size_t)(m1 * d) * 4, hipMemcpyHostToDevice, ctx->stream));
+    ICL_HIP(ctx, hipMemcpyAsync(gS.p, sizes, (size_t)m1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n > 2)
+        hipLaunchKernelGGL(udm_compact_kernel, dim3((unsigned)icl_ceil_div((n - 2) * (n - 2), 256)), dim3(256), 0, ctx->stream, (const float *)gD.p, n, ld,
+                           lo, hi, (float *)gO.p, m1);
+    hipLaunchKernelGGL(udm_newrow_kernel, dim3((unsigned)icl_ceil_div(m1, 128)), dim3(128), 0, ctx->stream, (const float *)gC.p, (const int32_t *)gS.p, m1,
+                       (int)d, (float *)gO.p, m1);
+    ICL_HIP(ctx, hipGetLastError());
+    ICL_HIP(ctx, hipMemcpy2DAsync(Dout, (size_t)ldout * 4, gO.p, (size_t)m1 * 4, (size_t)m1 * 4, (size_t)m1, hipMemcpyDeviceToHost, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICL_OK;
+}
+
 extern "C" int64_t icl_last_merge_values(icl_ctx *ctx, float *vals, int64_t cap)
 {
     if (!ctx) return -1;

@@ -82,7 +82,7 @@ def PreprocessImage(imagePath: str):
     """embeddings.go:46-116 -> (Mat, err): IMRead (baseline or progressive JPEG / binary PPM, decoded bit-identically to libjpeg-turbo) ->
     Resize 224x224 INTER_LINEAR -> RGB; Mat.Blob() gives the 1x3x224x224 fp32 blob scaled by 1/255."""
     try:
-        rgb = _lib.load_image_224(imagePath)
+        rgb = _lib.load_image_224(imagePath)  # IMRead (+ EXIF orientation) -> cv::resize -> RGB; icl_preprocess_file = this + Blob()
     except _lib.ICLError as e:
         return None, str(e).split(": ", 1)[-1]
     return Mat(rgb), None
@@ -92,11 +92,12 @@ def GetImageEmbedding(appCtx: AppContext, imagePath: str):
     """embeddings.go:119-163 -> (embedding []float32, err)."""
     if appCtx.Net is None or appCtx.Net.Empty():
         return None, "failed to generate embedding for image: %s" % imagePath
-    with appCtx.NetMutex:  # embeddings.go:133 (the engine is itself thread-safe; kept for signature parity)
-        try:
-            emb = appCtx.Net.ctx.embed_file(imagePath, appCtx.Head)
-        except _lib.ICLError as e:
-            return None, str(e)
+    # embeddings.go:133 serialises batch-1 forwards behind NetMutex; the engine instead COALESCES concurrent callers into one
+    # batched forward pass (icl_embed_file), so the mutex is kept as a field for signature parity but not taken here
+    try:
+        emb = appCtx.Net.ctx.embed_file(imagePath, appCtx.Head)
+    except _lib.ICLError as e:
+        return None, str(e)
     if emb.size == 0:
         return None, "embedding is empty for image: %s" % imagePath
     return emb, None

@@ -78,6 +78,12 @@ int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head
 /* One image file (baseline or progressive Huffman JPEG, or binary PPM "P6"): decode, bilinear resize to 224x224
  * (embeddings.go:69), then as icl_embed_u8 with n = 1, fp32. */
 int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
+/* icl_embed_file is what GetImageEmbedding(appCtx, path) binds to, and workflow.go:156-175 calls that from one goroutine per
+ * image.  Concurrent callers are coalesced: each decodes / resizes its own file, then one forward pass serves everything
+ * that queued up within window_us (or max_batch images).  prec selects ICL_PREC_FP32 (default: rows equal the one-at-a-time
+ * result bit for bit) or ICL_PREC_BF16.  window_us = 0 disables waiting (a lone caller runs at once). */
+int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch);
+int icl_file_batch_stats(icl_ctx *ctx, int64_t *batches, int64_t *images); /* forward passes run / images served by icl_embed_file */
 /* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, or binary PPM) to interleaved RGB.
  * With rgb == NULL only *w / *h are returned.  cap_bytes must be >= w*h*3. */
 int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h);
@@ -85,6 +91,11 @@ int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int
 int icl_load_image_224(const char *path, uint8_t *out);
 /* PreprocessImage alone: the 1x3x224x224 fp32 NCHW blob of embeddings.go:96-108 (host). */
 int icl_preprocess_u8(const uint8_t *hwc_rgb, float *nchw);
+/* PreprocessImage(imagePath) (embeddings.go:46-116) end to end on the host: IMRead (EXIF orientation applied, as cv::imread
+ * does) -> cv::resize(224x224, INTER_LINEAR; exact 2x2 decimation takes OpenCV's INTER_AREA path) -> RGB/255 NCHW fp32. */
+int icl_preprocess_file(const char *path, float *nchw);
+/* The resize step alone (embeddings.go:69) on an interleaved u8 RGB image: cv::resize(src, dst, (dw, dh), 0, 0, INTER_LINEAR). */
+int icl_resize_u8(const uint8_t *src_rgb, int32_t sw, int32_t sh, uint8_t *dst_rgb, int32_t dw, int32_t dh);
 int icl_set_batch(icl_ctx *ctx, int batch); /* embed batch size, 1..1024 */
 /* One fused convolution layer of the engine (the unit every ResNet50 conv is lowered to), host buffers:
  * y = relu?( conv(x, w) * scale[c] + shift[c] (+ residual) ).  x: [B][H][H][Cin] NHWC fp32, w: [Cout][Cin][k][k]
@@ -105,6 +116,11 @@ int icl_ward_distance_matrix_dev(icl_ctx *ctx, const float *d_C, const int32_t *
                                  float *d_D, int64_t ld);
 /* Centroid of MergeClusters(a,b) (clustering.go:37-40): (float(sa)*Ca + float(sb)*Cb)/float(sa+sb), host pointers. */
 int icl_merge_centroid(icl_ctx *ctx, const float *ca, int64_t sa, const float *cb, int64_t sb, int32_t d, float *out);
+/* UpdateDistanceMatrix (clustering.go:76-96) incl. RemoveRowsAndColumns (:100-116), host pointers.  D: n x n before the merge
+ * (leading dimension ld); r1, r2: positions of the merged clusters; C / sizes: the (n-1) clusters AFTER RemoveClusters +
+ * append (:240-241), new cluster last; Dout: (n-1) x (n-1), leading dimension ldout.  Bit-identical. */
+int icl_update_distance_matrix(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, const float *C, const int32_t *sizes,
+                               int32_t d, int64_t r1, int64_t r2, float *Dout, int64_t ldout);
 /* FindClosestClusters (clustering.go:119-133): first strict minimum of the lower triangle in row-major
  * order; (-1,-1) if none is < MaxFloat32. */
 int icl_find_closest(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, int64_t *i, int64_t *j);

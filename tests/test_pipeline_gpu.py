@@ -70,3 +70,54 @@ def test_concurrent_callers_share_one_context(ctx, L):
     assert not errs
     for i in range(12):
         assert np.array_equal(out[i], want[i])
+
+
+def test_get_image_embedding_from_64_goroutine_like_threads_is_coalesced(ctx, L, tmp_path):
+    """workflow.go:156-175 starts one goroutine per image, each calling GetImageEmbedding(appCtx, path).  The engine coalesces
+    those calls (icl_embed_file): 64 threads -> 64 results, each equal bit for bit to the row of ONE batched call on the same
+    decoded/resized images, from far fewer than 64 forward passes."""
+    from imageclust_amd import embeddings as EM
+
+    rng = np.random.default_rng(5)
+    paths = []
+    for i in range(64):
+        h, w = int(rng.integers(120, 400)), int(rng.integers(120, 400))
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = tmp_path / ("img_%d.ppm" % i)
+        with open(p, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (w, h) + arr.tobytes())
+        paths.append(str(p))
+    imgs = np.stack([L.load_image_224(p) for p in paths])
+    want = ctx.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_FP32)
+    app = EM.AppContext(Net=EM.Net(ctx), Head=L.HEAD_DENSE0)
+    ctx.set_file_options(L.PREC_FP32, 20000, 64)
+    before = ctx.file_batch_stats()
+    out, errs = [None] * 64, []
+    gate = threading.Barrier(64)
+
+    def worker(i):
+        try:
+            gate.wait()
+            out[i], err = EM.GetImageEmbedding(app, paths[i])
+            if err:
+                errs.append(err)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(64)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for i in range(64):
+        assert np.array_equal(out[i], want[i]), i
+    st = ctx.file_batch_stats()
+    assert st["images"] - before["images"] == 64
+    assert st["batches"] - before["batches"] <= 16, st  # coalesced: not one forward pass per image
+    # a lone caller is not held back longer than its window, and errors still surface per call
+    ctx.set_file_options(L.PREC_FP32, 0, 256)
+    assert np.array_equal(ctx.embed_file(paths[3], L.HEAD_DENSE0), want[3])
+    emb, err = EM.GetImageEmbedding(app, str(tmp_path / "missing.jpg"))
+    assert emb is None and "failed to read image" in err
+    ctx.set_file_options(L.PREC_FP32, 2000, 256)

@@ -397,3 +397,49 @@ def test_golden_fixtures(ctx):
         cid, rank, _ = ctx.cluster(t["E"], mn, mx)
         assert np.array_equal(cid, t["cid_%d_%d" % (mn, mx)]) and np.array_equal(rank, t["rank_%d_%d" % (mn, mx)])
         assert np.array_equal(ctx.last_merges(), t["merges_%d_%d" % (mn, mx)])
+
+
+def test_update_distance_matrix_three_step_replay(ctx, CL):
+    """icl_update_distance_matrix == UpdateDistanceMatrix (clustering.go:76-96) + RemoveRowsAndColumns (:100-116): drive the
+    reference's own loop (:220-246) for three merges, the engine's matrix against the literal procedure built from the
+    oracle's WardDistance / MergeClusters helpers, bit for bit after every step."""
+    rng = np.random.default_rng(12)
+    n, d = 14, 9
+    E = rng.standard_normal((n, d)).astype(np.float32)
+    clusters = [CL.NewCluster(i, E[i]) for i in range(n)]
+    D = CL.ComputeInitialDistanceMatrix(clusters, ctx)
+    R = O.initial_distance_matrix(E)
+    assert np.array_equal(D.view(np.uint32), R.view(np.uint32))
+    ref_c = [(E[i].copy(), 1) for i in range(n)]
+    for step in range(3):
+        i, j = CL.FindClosestClusters(D, ctx)
+        assert (i, j) == O.find_closest(R) and i > j
+        new = CL.MergeClusters(clusters[i], clusters[j], ctx)                       # :237
+        clusters = CL.RemoveClusters(clusters, i, j) + [new]                        # :240-241
+        D = CL.UpdateDistanceMatrix(D, clusters, new, i, j, ctx)                     # :244
+        # literal reference procedure on the oracle side
+        (ca, sa), (cb, sb) = ref_c[i], ref_c[j]
+        nc = (O.merge_centroid(ca, sa, cb, sb), sa + sb)
+        ref_c = [c for k, c in enumerate(ref_c) if k not in (i, j)] + [nc]
+        keep = [k for k in range(R.shape[0]) if k not in (i, j)]
+        R2 = np.zeros((len(keep) + 1, len(keep) + 1), np.float32)
+        R2[:-1, :-1] = R[np.ix_(keep, keep)]
+        for k in range(len(keep)):
+            R2[k, -1] = R2[-1, k] = O.ward_distance(ref_c[k][0], ref_c[k][1], nc[0], nc[1])
+        R = R2
+        assert D.shape == R.shape == (n - 1 - step, n - 1 - step)
+        assert np.array_equal(D.view(np.uint32), R.view(np.uint32)), "step %d" % step
+        assert np.array_equal(new.Centroid, nc[0]) and new.Size == nc[1]
+    # positions given in either order, and the degenerate n = 2 case
+    D2 = ctx.update_distance_matrix(np.array([[0, 3], [3, 0]], np.float32), np.array([[1.0, 2.0]], np.float32), [2], 1, 0)
+    assert D2.shape == (1, 1) and D2[0, 0] == 0
+    with pytest.raises(Exception):
+        ctx.update_distance_matrix(np.zeros((3, 3), np.float32), np.zeros((2, 2), np.float32), [1, 1], 1, 1)
+
+
+def test_dot_float32_mirror(CL):
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal(333).astype(np.float32), rng.standard_normal(333).astype(np.float32)
+    assert CL.DotFloat32(a, b).view(np.uint32) == np.float32(O.lib().icl_ref_dot(a, b, 333)).view(np.uint32)
+    with pytest.raises(ValueError):
+        CL.DotFloat32(a, b[:5])
