@@ -8,7 +8,8 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
 The workload is the one BASELINE.json's metric is quoted on: "images/sec (embed+Ward) on 100k 224x224 imgs at 1/2/4/8
 MI355X" -- 100 000 synthetic images (configs[2]'s N; it fits one 288 GB GPU: 15 GB of images, 80 GB distance triangle).
 N=1 runs the whole job on one GPU; N>1 STRONG-scales the same 100 000-image job: the images are sharded over the ranks
-for the embed, E is all-gathered, rank 0 clusters it (configs[2]'s shape: "Ward on GPU0").  `--total-images 10000` is
+for the embed, E is all-gathered, every rank computes its share of the initial distance matrix and sends it to rank 0
+over xGMI, rank 0 runs the exact merge loop (configs[2]'s shape: "Ward on GPU0").  `--total-images 10000` is
 configs[1] (its line is quoted in README.md); `--scaling weak` keeps --images-per-gpu images PER GPU instead.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
@@ -193,7 +194,20 @@ def main():
             result["allgather_ms"] = (time.perf_counter() - t0) * 1e3
         if args.embed_only:
             return
-        if rank == 0:
+        if world > 1 and args.update == "exact":
+            # the initial distance matrix is built on ALL ranks (area-balanced runs of tile rows), every span goes to rank 0's
+            # triangle over xGMI (point-to-point sends, no collective), rank 0 runs the exact merge loop
+            t0 = time.perf_counter()
+            res = D.cluster_with_distributed_tiles(ctx, E_full, args.min_size, args.max_size, rank, world, update,
+                                                   staged=(args.dist_backend == "gloo"))
+            if rank == 0:
+                keep["E_full"] = E_full
+                cid, mrank, nc = res
+                st = ctx.last_stage_ms()
+                total_ms = (time.perf_counter() - t0) * 1e3
+                result.update(dist_ms=total_ms - st["merge_ms"], merge_ms=st["merge_ms"], n_clusters=nc, merges=len(ctx.last_merges()),
+                              dropped=int((cid < 0).sum()))
+        elif rank == 0:
             keep["E_full"] = E_full  # rank 0 re-uses the gathered matrix for the untimed profiling pass (no second collective)
             cid, mrank, nc = ctx.cluster_dev(E_full.data_ptr(), n_total, DIM, args.min_size, args.max_size, update)
             st = ctx.last_stage_ms()
@@ -309,10 +323,10 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 bf16 "
-                                   "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d on GPU0 -> cluster ids on host"
+                                   "batch=%d -> 2048-d pooled E%s -> Ward min=%d max=%d (merge loop on GPU0) -> cluster ids on host"
                                    % ("the metric's size (configs[2]'s N=100000) on %d GPU%s" % (world, "s" if world > 1 else "") if n_total == 100000
                                       else "configs[1]" if n_total == 10000 and world == 1 else "custom size",
-                                      n_total, n_local, args.batch, " -> RCCL all-gather" if world > 1 else "", args.min_size, args.max_size),
+                                      n_total, n_local, args.batch, " -> RCCL all-gather -> distance rows on all ranks, spans sent to GPU0" if world > 1 else "", args.min_size, args.max_size),
                        "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
                        "ward_update": "exact (ids bit-identical to the reference)" if args.update == "exact"
                        else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},

@@ -61,6 +61,23 @@ SYMBOLS = [
     ("icl_update_distance_matrix", _int, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i64, _vp, _i64]),
     ("icl_find_closest", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
     ("icl_find_closest_dev", _int, [_vp, _vp, _i64, _i64, _pi64, _pi64]),
+    ("icl_group_create", _int, [_pi32, _i32, C.POINTER(_vp)]),
+    ("icl_group_destroy", None, [_vp]),
+    ("icl_group_size", _i32, [_vp]),
+    ("icl_group_ctx", _vp, [_vp, _i32]),
+    ("icl_group_last_error", C.c_char_p, [_vp]),
+    ("icl_group_load_onnx", _int, [_vp, C.c_char_p]),
+    ("icl_group_load_blob", _int, [_vp, _vp, _i64]),
+    ("icl_group_load_synthetic", _int, [_vp, C.c_uint64]),
+    ("icl_group_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
+    ("icl_group_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_ward_rows_partition", _int, [_i64, _i32, _i32, _pi64, _pi64]),
+    ("icl_ward_span", _int, [_i64, _i64, _pi64, _pi64]),
+    ("icl_ward_distance_rows_dev", _int, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
+    ("icl_ward_prepare", _int, [_vp, _i64, _i32]),
+    ("icl_ward_span_ptr", _int, [_vp, _i64, _i64, C.POINTER(_vp), _pi64]),
+    ("icl_ward_deposit_dev", _int, [_vp, _i64, _i64, _vp]),
+    ("icl_cluster_prefilled_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _i64, _i64, _vp, _vp, _pi32]),
     ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_cluster_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_last_merges", _i64, [_vp, _vp, _i64]),
@@ -313,6 +330,30 @@ class Context:
                                              rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
 
+    # ---- distance tiles over several GPUs (building blocks; imageclust_amd/distributed.py and Group use them) ----
+    def ward_prepare(self, n, d):
+        check(self.h, self.L.icl_ward_prepare(self.h, n, d))
+
+    def ward_span_ptr(self, row_lo, row_hi):
+        """(device pointer, floats) of rows [row_lo, row_hi) inside this context's packed distance triangle."""
+        p, c = _vp(), _i64()
+        check(self.h, self.L.icl_ward_span_ptr(self.h, row_lo, row_hi, C.byref(p), C.byref(c)))
+        return p.value, c.value
+
+    def ward_distance_rows_dev(self, d_E, n, d, row_lo, row_hi, d_span):
+        check(self.h, self.L.icl_ward_distance_rows_dev(self.h, _vp(d_E), n, d, row_lo, row_hi, _vp(d_span)))
+
+    def ward_deposit_dev(self, row_lo, row_hi, d_span):
+        check(self.h, self.L.icl_ward_deposit_dev(self.h, row_lo, row_hi, _vp(d_span)))
+
+    def cluster_prefilled_dev(self, d_E, n, d, min_size, max_size, own_lo, own_hi, update=UPDATE_EXACT):
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        check(self.h, self.L.icl_cluster_prefilled_dev(self.h, _vp(d_E), n, d, min_size, max_size, update, own_lo, own_hi,
+                                                       cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
+        return cid[:n], rank[:n], nc.value
+
     def distance_mfma(self, E):
         """MFMA distance tile (K6): lower triangle (incl. zero diagonal) of 0.5*|e_i-e_j|^2, n x n fp32."""
         E = np.ascontiguousarray(E, np.float32)
@@ -340,6 +381,70 @@ class Context:
         out = np.zeros(max(n, 1), np.float32)
         self.L.icl_last_merge_values(self.h, out.ctypes.data, n)
         return out[:n]
+
+
+def ward_rows_partition(n, parts, part):
+    """Rows [lo, hi) of the initial distance matrix that part `part` of `parts` computes: whole 128-row tile rows, equal AREA."""
+    lo, hi = _i64(), _i64()
+    rc = load().icl_ward_rows_partition(n, parts, part, C.byref(lo), C.byref(hi))
+    if rc:
+        raise ICLError(rc, "icl_ward_rows_partition")
+    return lo.value, hi.value
+
+
+def ward_span(row_lo, row_hi):
+    """(float offset, float count) of rows [row_lo, row_hi) in the packed lower triangle (rows padded to 4 floats)."""
+    off, cnt = _i64(), _i64()
+    rc = load().icl_ward_span(row_lo, row_hi, C.byref(off), C.byref(cnt))
+    if rc:
+        raise ICLError(rc, "icl_ward_span")
+    return off.value, cnt.value
+
+
+class Group:
+    """Several GPUs behind one handle (icl_group_*): one process, one context + host thread per GPU."""
+
+    def __init__(self, devices):
+        self.L = load()
+        self.g = _vp()
+        dv = (C.c_int32 * len(devices))(*devices)
+        rc = self.L.icl_group_create(dv, len(devices), C.byref(self.g))
+        if rc:
+            raise ICLError(rc, (self.L.icl_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc:
+            raise ICLError(rc, (self.L.icl_group_last_error(self.g) or b"").decode())
+
+    def close(self):
+        if self.g:
+            self.L.icl_group_destroy(self.g)
+            self.g = _vp()
+
+    def size(self):
+        return self.L.icl_group_size(self.g)
+
+    def load_synthetic(self, seed=1):
+        self._check(self.L.icl_group_load_synthetic(self.g, seed))
+
+    def load_blob(self, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(self.L.icl_group_load_blob(self.g, C.addressof(buf), len(blob)))
+
+    def embed_u8(self, imgs, head=HEAD_POOLED, prec=PREC_BF16):
+        imgs = np.ascontiguousarray(imgs, np.uint8).reshape(-1, IMG_BYTES)
+        out = np.empty((imgs.shape[0], head), np.float32)
+        self._check(self.L.icl_group_embed_u8(self.g, imgs.ctypes.data, imgs.shape[0], head, prec, out.ctypes.data))
+        return out
+
+    def cluster(self, E, min_size, max_size, update=UPDATE_EXACT):
+        E = np.ascontiguousarray(E, np.float32)
+        n, d = E.shape
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        self._check(self.L.icl_group_cluster(self.g, E.ctypes.data, n, d, min_size, max_size, update, cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
+        return cid[:n], rank[:n], nc.value
 
 
 def calc_optimal_clusters(total, min_size, max_size):

@@ -47,6 +47,8 @@ struct icl_ctx {
     // subsystems
     icl_model *model = nullptr;
     icl_ward_ws *ward = nullptr;
+    int64_t *ward_rowoff = nullptr; // row offsets of the packed triangle for ranks that only compute distance rows (ward.hip)
+    int64_t ward_rowoff_n = 0;
     void *file_batcher = nullptr; // icl_embed_file's coalescing queue (resnet.hip)
     std::vector<int32_t> last_merges; // pairs
     std::vector<float> last_merge_vals; // Ward distance of each merged pair

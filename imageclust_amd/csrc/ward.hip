@@ -115,6 +115,9 @@ struct icl_ward_ws {
 
 void icl_ward_free(icl_ctx *ctx)
 {
+    if (ctx->ward_rowoff) (void)hipFree(ctx->ward_rowoff);
+    ctx->ward_rowoff = nullptr;
+    ctx->ward_rowoff_n = 0;
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
@@ -147,12 +150,12 @@ __device__ __forceinline__ void tri_decode(int64_t b, int &ti, int &tj)
 template <int MODE>
 __global__ __launch_bounds__(256) void ward_dist_exact_kernel(const float *__restrict__ X, const int32_t *__restrict__ sizes,
                                                              int64_t n, int d, float *__restrict__ out,
-                                                             const int64_t *__restrict__ rowoff, int64_t ld)
+                                                             const int64_t *__restrict__ rowoff, int64_t ld, int64_t block_base)
 {
     __shared__ __attribute__((aligned(16))) float As[DT_KC][DT_LD];
     __shared__ __attribute__((aligned(16))) float Bs[DT_KC][DT_LD];
     int ti, tj;
-    tri_decode(blockIdx.x, ti, tj);
+    tri_decode(block_base + blockIdx.x, ti, tj); // block_base > 0: a run of whole tile rows (a rank's share of the triangle)
     const int64_t i0 = (int64_t)ti * DT_TILE, j0 = (int64_t)tj * DT_TILE;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -2929,6 +2932,25 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     return ICL_OK;
 }
 
+// A rank that only computes distance rows needs the row-offset table, not the 8 n^2-byte triangle.
+static int ward_ensure_rowoff(icl_ctx *ctx, int64_t n)
+{
+    if (ctx->ward_rowoff && ctx->ward_rowoff_n >= n) return ICL_OK;
+    if (ctx->ward_rowoff) (void)hipFree(ctx->ward_rowoff);
+    ctx->ward_rowoff = nullptr;
+    std::vector<int64_t> h((size_t)n + 2);
+    int64_t off = 0;
+    for (int64_t r = 0; r <= n + 1; ++r) {
+        h[(size_t)r] = off;
+        off += (r + 3) / 4 * 4;
+    }
+    ICL_HIP(ctx, hipMalloc((void **)&ctx->ward_rowoff, h.size() * sizeof(int64_t)));
+    ICL_HIP(ctx, hipMemcpyAsync(ctx->ward_rowoff, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ward_rowoff_n = n;
+    return ICL_OK;
+}
+
 static int fc_ensure(icl_ctx *ctx, int64_t n)
 {
     if (!ctx->ward) ctx->ward = new icl_ward_ws();
@@ -2960,23 +2982,31 @@ extern "C" int icl_calc_optimal_clusters(int64_t total, int64_t min_size, int64_
     return ICL_OK;
 }
 
+// Tile rows [tr_lo, tr_hi) of the lower triangle (tile row ti holds ti+1 tiles of 128 x 128 pairs).  In mode 0 `out` is the
+// address row 0 of the packed triangle WOULD have: a caller that holds only the span of its own rows passes span - rowoff[first row].
+static int launch_dist_exact_rows(icl_ctx *ctx, const float *d_X, const int32_t *d_sizes, int64_t n, int d, float *out,
+                                  const int64_t *rowoff, int64_t ld, int mode, int64_t tr_lo, int64_t tr_hi)
+{
+    if (n <= 0 || tr_hi <= tr_lo) return ICL_OK;
+    const int64_t b_lo = tr_lo * (tr_lo + 1) / 2, nblocks = tr_hi * (tr_hi + 1) / 2 - b_lo;
+    if (nblocks > 0x7fffffffLL) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "distance tile grid too large (n=%lld)", (long long)n);
+    const int64_t r_lo = tr_lo * DT_TILE, r_hi = std::min<int64_t>(tr_hi * DT_TILE, n);
+    const double pairs = 0.5 * ((double)r_hi * (double)(r_hi - 1) - (double)r_lo * (double)(r_lo - 1));
+    icl_prof_scope ps(ctx, ICL_K_DIST_EXACT, pairs * 3.0 * d, 4.0 * r_hi * d + 4.0 * pairs);
+    if (mode == 0)
+        hipLaunchKernelGGL(ward_dist_exact_kernel<0>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
+                           out, rowoff, ld, b_lo);
+    else
+        hipLaunchKernelGGL(ward_dist_exact_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
+                           out, rowoff, ld, b_lo);
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}
+
 static int launch_dist_exact(icl_ctx *ctx, const float *d_X, const int32_t *d_sizes, int64_t n, int d, float *out,
                              const int64_t *rowoff, int64_t ld, int mode)
 {
-    if (n <= 0) return ICL_OK;
-    const int64_t nt = icl_ceil_div(n, DT_TILE);
-    const int64_t nblocks = nt * (nt + 1) / 2;
-    if (nblocks > 0x7fffffffLL) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "distance tile grid too large (n=%lld)", (long long)n);
-    const double pairs = (double)n * (double)(n - 1) * 0.5;
-    icl_prof_scope ps(ctx, ICL_K_DIST_EXACT, pairs * 3.0 * d, 4.0 * n * d + 4.0 * pairs);
-    if (mode == 0)
-        hipLaunchKernelGGL(ward_dist_exact_kernel<0>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
-                           out, rowoff, ld);
-    else
-        hipLaunchKernelGGL(ward_dist_exact_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
-                           out, rowoff, ld);
-    ICL_HIP(ctx, hipGetLastError());
-    return ICL_OK;
+    return launch_dist_exact_rows(ctx, d_X, d_sizes, n, d, out, rowoff, ld, mode, 0, icl_ceil_div(n, DT_TILE));
 }
 
 extern "C" int icl_ward_distance_matrix_dev(icl_ctx *ctx, const float *d_C, const int32_t *d_sizes, int64_t n, int32_t d,
@@ -3117,8 +3147,11 @@ static int assign_ids(icl_ctx *ctx, int64_t n, int32_t min_size, int32_t max_siz
     return rc;
 }
 
+// own_lo / own_hi: rows of the initial distance matrix this call computes itself (whole 128-row tile rows; everything by
+// default).  The other rows must already sit in the triangle (icl_ward_deposit_dev): the multi-GPU paths compute them on
+// the other GPUs and send them here over xGMI.
 static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
-                          int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+                          int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters, int64_t own_lo = 0, int64_t own_hi = -1)
 {
     int64_t k = 0;
     if (icl_calc_optimal_clusters(n, min_size, max_size, &k) != ICL_OK)
@@ -3160,10 +3193,14 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ICL_HIP(ctx, hipGetLastError());
     }
     // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle: exact tile, or the MFMA tile in FAST mode
-    if (lw)
+    if (own_hi < 0) own_hi = n;
+    if (own_lo < 0 || own_lo > own_hi || own_hi > n || own_lo % DT_TILE || (own_hi % DT_TILE && own_hi != n))
+        return icl_fail(ctx, ICL_ERR_ARG, "own rows [%lld, %lld) must be whole 128-row tile rows of [0, %lld)", (long long)own_lo, (long long)own_hi, (long long)n);
+    if (lw) {
+        if (own_lo != 0 || own_hi != n) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "FAST mode builds the whole distance matrix on one GPU");
         ICL_TRY(icl_dist_mfma_launch(ctx, d_E, n, d, w->Dtri, w->rowoff, 0));
-    else
-        ICL_TRY(launch_dist_exact(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0));
+    } else
+        ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0, own_lo / DT_TILE, icl_ceil_div(own_hi, DT_TILE)));
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
@@ -3400,6 +3437,109 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     int rc = assign_ids(ctx, n, min_size, max_size, pairs, nmerge, cluster_id, member_rank, n_clusters);
     ctx->last_merges.swap(pairs);
     return rc;
+}
+
+// ---- distance tiles over several GPUs ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI") ----------
+// The packed triangle stores its rows back to back, so a run of rows [lo, hi) is ONE contiguous span of floats: a GPU
+// computes the span of its own rows into a buffer of that size and the span is copied (peer copy / RCCL send) to the same
+// offset of the clustering GPU's triangle.  Rows are dealt in whole 128-row tile rows, balanced by AREA (tile row ti
+// has ti+1 tiles), not by row count.
+static int64_t tri_rowoff(int64_t r) // float offset of row r: rows are padded to 4 floats -> sum_{q<r} 4*ceil(q/4)
+{
+    // row 0 holds nothing, rows 4k+1 .. 4k+4 hold 4(k+1) floats each: sum over rows 1 .. r-1 = full groups of four + the partial group
+    if (r <= 0) return 0;
+    const int64_t q = r - 1, g = q / 4, p = q % 4;
+    return 16 * g * (g + 1) / 2 + p * 4 * (g + 1);
+}
+
+extern "C" int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi)
+{
+    if (n < 0 || parts < 1 || part < 0 || part >= parts || !row_lo || !row_hi) return icl_fail(nullptr, ICL_ERR_ARG, "icl_ward_rows_partition: bad argument");
+    const int64_t nt = icl_ceil_div(n, DT_TILE), total = nt * (nt + 1) / 2;
+    auto bound = [&](int64_t p) -> int64_t { // first tile row whose preceding area reaches p/parts of the total
+        if (p <= 0) return 0;
+        if (p >= parts) return nt;
+        const double want = (double)total * (double)p / (double)parts;
+        int64_t t = (int64_t)((std::sqrt(8.0 * want + 1.0) - 1.0) * 0.5);
+        while (t * (t + 1) / 2 < want) ++t;
+        while (t > 0 && (t - 1) * t / 2 >= want) --t;
+        return std::min(t, nt);
+    };
+    *row_lo = std::min<int64_t>(bound(part) * DT_TILE, n);
+    *row_hi = std::min<int64_t>(bound(part + 1) * DT_TILE, n);
+    return ICL_OK;
+}
+
+extern "C" int icl_ward_span(int64_t row_lo, int64_t row_hi, int64_t *float_off, int64_t *float_cnt)
+{
+    if (row_lo < 0 || row_hi < row_lo || !float_off || !float_cnt) return icl_fail(nullptr, ICL_ERR_ARG, "icl_ward_span: bad argument");
+    *float_off = tri_rowoff(row_lo);
+    *float_cnt = tri_rowoff(row_hi) - tri_rowoff(row_lo);
+    return ICL_OK;
+}
+
+// Rows [row_lo, row_hi) of ComputeInitialDistanceMatrix (clustering.go:61-73, singleton clusters) into d_span, laid out as
+// that span of the packed triangle.  row_lo must be a multiple of 128, row_hi a multiple of 128 or n.
+extern "C" int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int64_t row_lo, int64_t row_hi, float *d_span)
+{
+    if (!ctx || n < 0 || d < 0 || row_lo < 0 || row_hi < row_lo || row_hi > n || (n && !d_E) || (row_hi > row_lo && !d_span) || row_lo % DT_TILE ||
+        (row_hi % DT_TILE && row_hi != n))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_distance_rows_dev: bad argument (rows must be whole 128-row tile rows)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_TRY(ward_ensure_rowoff(ctx, n));
+    ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, d_span - tri_rowoff(row_lo), ctx->ward_rowoff, 0, 0, row_lo / DT_TILE,
+                                   icl_ceil_div(row_hi, DT_TILE)));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICL_OK;
+}
+
+// Allocates the clustering workspace for (n, d) and returns where rows [row_lo, row_hi) of the distance triangle live on this
+// GPU, so that a transport (RCCL recv, peer copy) can write another GPU's span straight into place.
+extern "C" int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d)
+{
+    if (!ctx || n < 0 || d < 0) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_prepare: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    return ward_ensure(ctx, n, d);
+}
+
+extern "C" int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt)
+{
+    if (!ctx || !d_ptr || !float_cnt || row_lo < 0 || row_hi < row_lo) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_span_ptr: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->ward || !ctx->ward->Dtri || row_hi > ctx->ward->capN) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_span_ptr: call icl_ward_prepare(n, d) first");
+    *d_ptr = ctx->ward->Dtri + tri_rowoff(row_lo);
+    *float_cnt = tri_rowoff(row_hi) - tri_rowoff(row_lo);
+    return ICL_OK;
+}
+
+// Copies a span computed elsewhere (this or another GPU: peer copy) into the triangle.
+extern "C" int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span)
+{
+    void *dst = nullptr;
+    int64_t cnt = 0;
+    ICL_TRY(icl_ward_span_ptr(ctx, row_lo, row_hi, &dst, &cnt));
+    if (cnt == 0) return ICL_OK;
+    if (!d_span) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_deposit_dev: null span");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    ICL_HIP(ctx, hipMemcpyAsync(dst, d_span, (size_t)cnt * 4, hipMemcpyDefault, ctx->stream));
+    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICL_OK;
+}
+
+// icl_cluster_dev where the caller has already deposited every row of the initial distance matrix outside [own_lo, own_hi).
+extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                                         int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!d_E || !cluster_id || !member_rank)))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    if (!ctx->ward || ctx->ward->capN != n || ctx->ward->capD != d)
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: call icl_ward_prepare(n, d) and deposit the foreign rows first");
+    return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, own_lo, own_hi);
 }
 
 extern "C" int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,

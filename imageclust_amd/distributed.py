@@ -3,7 +3,11 @@ rendezvous and the one real exchange step of the path -- assembling E on every r
 
 * embed shards naturally: rank r owns the contiguous image range shard_range(n_total, r, world); no collective.
 * E is assembled with ONE all-gather (backend "nccl" == RCCL over xGMI on MI355X; "gloo" on CPU in the tests).
-* Ward runs on rank 0 over the gathered E (BASELINE.json configs[2]: "tiled Ward distance on GPU0").
+* the initial distance matrix (clustering.go:61-73) is built on ALL ranks: rank r computes an area-balanced run of
+  128-row tile rows (one contiguous span of the packed triangle) and sends it to rank 0, which receives it straight into its
+  triangle ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI"); rank 0 computes its own run
+  meanwhile.  No data-path collective: 7 point-to-point sends, one per xGMI link into GPU 0.
+* the exact merge loop runs on rank 0 (BASELINE.json configs[2]: "tiled Ward distance on GPU0").
 
 Nothing here computes on tensors: device work stays in libimageclust_hip.so.
 """
@@ -58,6 +62,76 @@ def gather_embeddings(E_local: torch.Tensor, n_total: int, rank: int, world: int
         lo, hi = shard_range(n_total, r, world)
         parts.append(buf[r * cap: r * cap + (hi - lo)])
     return torch.cat(parts, 0)
+
+
+class _DeviceSpan:
+    """Lets torch address `count` floats of engine-owned device memory without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def tile_plan(n: int, world: int):
+    """[(row_lo, row_hi, float_off, float_cnt)] per rank: who computes which rows of the initial distance matrix."""
+    from . import _lib
+
+    plan = []
+    for r in range(world):
+        lo, hi = _lib.ward_rows_partition(n, world, r)
+        off, cnt = _lib.ward_span(lo, hi)
+        plan.append((lo, hi, off, cnt))
+    return plan
+
+
+def exchange_spans(rank: int, world: int, plan, my_span, recv_buffer):
+    """The one exchange of the distance build: every rank r > 0 sends its span to rank 0.  On rank 0 recv_buffer(r) returns
+    the tensor the span of rank r lands in (for the GPU path: a view of the triangle itself).  Returns the pending requests
+    (rank 0) so the caller can compute its own rows while the transfers run."""
+    if world <= 1:
+        return []
+    if rank != 0:
+        if plan[rank][3] > 0:
+            dist.send(my_span, dst=0)
+        return []
+    return [dist.irecv(recv_buffer(r), src=r) for r in range(1, world) if plan[r][3] > 0]
+
+
+def cluster_with_distributed_tiles(ctx, E_full: torch.Tensor, min_size: int, max_size: int, rank: int, world: int, update=0, staged=False):
+    """PerformClusteringWithConstraints over `world` GPUs: distance rows on every rank, merge loop on rank 0.
+    Returns (cluster_id, member_rank, n_clusters) on rank 0 and None elsewhere.  staged=True moves the spans through host
+    memory (gloo rehearsal on a box whose ranks share one GPU)."""
+    n, d = E_full.shape
+    plan = tile_plan(n, world)
+    lo, hi, _, cnt = plan[rank]
+    if rank != 0:
+        span = torch.empty(max(cnt, 1), dtype=torch.float32, device=E_full.device)
+        if cnt:
+            ctx.ward_distance_rows_dev(E_full.data_ptr(), n, d, lo, hi, span.data_ptr())
+        exchange_spans(rank, world, plan, span[:cnt].cpu() if staged else span[:cnt], None)
+        return None
+    ctx.ward_prepare(n, d)
+    views = {}
+
+    def recv_buffer(r):
+        if staged:
+            views[r] = torch.empty(plan[r][3], dtype=torch.float32)
+        else:
+            ptr, c = ctx.ward_span_ptr(plan[r][0], plan[r][1])
+            views[r] = torch.as_tensor(_DeviceSpan(ptr, c), device=E_full.device)
+        return views[r]
+
+    reqs = exchange_spans(rank, world, plan, None, recv_buffer)
+    if cnt:  # rank 0's own rows, written into its triangle while the other spans arrive
+        ptr, _ = ctx.ward_span_ptr(lo, hi)
+        ctx.ward_distance_rows_dev(E_full.data_ptr(), n, d, lo, hi, ptr)
+    for q in reqs:
+        q.wait()
+    if staged:
+        for r, t in views.items():
+            dev = t.to(E_full.device)
+            ctx.ward_deposit_dev(plan[r][0], plan[r][1], dev.data_ptr())
+    torch.cuda.synchronize()
+    return ctx.cluster_prefilled_dev(E_full.data_ptr(), n, d, min_size, max_size, 0, 0, update)
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

@@ -12,8 +12,8 @@
  *     live on the context's GPU and are consumed on the context's stream (icl_stream()).
  *   - all entry points are thread-safe (a context serialises its own calls with a mutex): the reference calls
  *     GetImageEmbedding from N goroutines (internal/workflow/workflow.go:156-175).
- *   - one context drives ONE GPU; multi-GPU jobs run one process (or one context) per GPU and exchange E with
- *     RCCL outside this ABI (bench.py, imageclust_amd/distributed.py).
+ *   - one context drives ONE GPU.  Several GPUs: an icl_group (one process, one context + host thread per GPU, peer copies
+ *     over xGMI), or one process per GPU with the icl_ward_* span calls and RCCL as the transport (bench.py).
  */
 #ifndef IMAGECLUST_H
 #define IMAGECLUST_H
@@ -104,6 +104,35 @@ int icl_set_batch(icl_ctx *ctx, int batch); /* embed batch size, 1..1024 */
 int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int Cin, const float *w, int Cout, int k,
                      int stride, int pad, const float *scale, const float *shift, const float *residual, int relu,
                      float *y);
+
+/* ---- several GPUs behind one handle ------------------------------------------------------------------
+ * workflow.go:89,161 run in ONE process: a group drives ndev contexts from ndev host threads.  embed shards the images by
+ * contiguous index ranges; cluster computes the initial distance rows (clustering.go:61-73) on every GPU in area-balanced
+ * runs of 128-row tile rows, copies each span device-to-device into GPU 0's packed triangle and runs the exact merge loop
+ * on GPU 0.  Outputs are bit-identical to the single-GPU calls.  devices[] entries may repeat (tests on a 1-GPU box). */
+typedef struct icl_group icl_group;
+int icl_group_create(const int32_t *devices, int32_t ndev, icl_group **out);
+void icl_group_destroy(icl_group *g);
+int32_t icl_group_size(icl_group *g);
+icl_ctx *icl_group_ctx(icl_group *g, int32_t i); /* borrowed: context of GPU i for per-device calls */
+const char *icl_group_last_error(icl_group *g);
+int icl_group_load_onnx(icl_group *g, const char *path);
+int icl_group_load_blob(icl_group *g, const void *blob, int64_t bytes);
+int icl_group_load_synthetic(icl_group *g, uint64_t seed);
+int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
+int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                      int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+
+/* The building blocks of the above, for callers that bring their own transport (bench.py: one process per GPU, RCCL
+ * send/recv).  Rows [row_lo, row_hi) of the packed lower triangle are ONE contiguous span of floats. */
+int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi); /* area-balanced, whole 128-row tile rows */
+int icl_ward_span(int64_t row_lo, int64_t row_hi, int64_t *float_off, int64_t *float_cnt);             /* where that span sits / how long it is */
+int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int64_t row_lo, int64_t row_hi, float *d_span);
+int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d);                                              /* allocate the clustering workspace */
+int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt);  /* receive foreign spans here */
+int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span);           /* ... or copy them in */
+int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                              int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 
 /* ---- Ward clustering: replaces internal/clustering/clustering.go --------------------------------------- */
 /* CalculateOptimalClusters (clustering.go:168-186). ICL_ERR_CONSTRAINT on the reference's error branches. */

@@ -62,3 +62,76 @@ def test_shard_ranges_partition():
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- distance tiles over ranks (imageclust_amd/distributed.py: tile_plan / exchange_spans) ---------------------------
+def _pack_rows(D, lo, hi):
+    """Rows [lo, hi) of a dense matrix in the engine's packed-triangle layout: row r holds D[r, :r], padded to 4 floats."""
+    out = []
+    for r in range(lo, hi):
+        row = np.zeros((r + 3) // 4 * 4, np.float32)
+        row[:r] = D[r, :r]
+        out.append(row)
+    return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+def test_tile_plan_covers_the_triangle_with_balanced_area():
+    from imageclust_amd import _lib
+
+    for n in [0, 1, 127, 128, 129, 1000, 10000, 100000, 250000]:
+        for w in [1, 2, 3, 8]:
+            plan = D.tile_plan(n, w)
+            assert plan[0][0] == 0 and plan[-1][1] == n
+            off = 0
+            for (lo, hi, o, c) in plan:
+                assert (lo % 128 == 0 or lo == n) and (hi % 128 == 0 or hi == n) and lo <= hi
+                assert o == off  # spans tile the packed triangle back to back
+                off += c
+            assert off == _lib.ward_span(0, n)[1] == sum((r + 3) // 4 * 4 for r in range(n))
+            if n >= 100000:  # equal AREA, not equal row counts: the first rank gets ~sqrt(1/w) of the rows
+                areas = [c for (_, _, _, c) in plan]
+                assert max(areas) / (sum(areas) / w) < 1.05
+                assert plan[0][1] - plan[0][0] > 2 * (plan[-1][1] - plan[-1][0]) or w == 1
+
+
+def _span_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    D.init("gloo", rank, world)
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(7)
+    E = rng.standard_normal((n, 6)).astype(np.float32)  # every rank holds the gathered E
+    full = O.initial_distance_matrix(E)
+    plan = D.tile_plan(n, world)
+    lo, hi, off, cnt = plan[rank]
+    mine = torch.from_numpy(_pack_rows(full, lo, hi))  # stands in for icl_ward_distance_rows_dev on this rank's GPU
+    assert mine.numel() == cnt
+    ok = True
+    if rank == 0:
+        tri = torch.zeros(sum(p[3] for p in plan), dtype=torch.float32)
+        tri[off:off + cnt] = mine
+        reqs = D.exchange_spans(rank, world, plan, None, lambda r: tri[plan[r][2]:plan[r][2] + plan[r][3]])
+        for rq in reqs:
+            rq.wait()
+        ok = bool(torch.equal(tri, torch.from_numpy(_pack_rows(full, 0, n))))  # rank 0 now holds exactly the packed triangle
+    else:
+        D.exchange_spans(rank, world, plan, mine, None)
+    D.barrier()
+    q.put((rank, ok))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 700), (2, 129)])
+def test_span_exchange_assembles_the_packed_triangle_gloo(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_span_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

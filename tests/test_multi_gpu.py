@@ -1,0 +1,140 @@
+"""Several GPUs behind the C-ABI (include/imageclust.h: icl_group_*, icl_ward_*span*): the group path and the
+process-per-GPU building blocks must reproduce the single-GPU results bit for bit.  The box has ONE GPU, so the groups
+here hold several contexts on device 0 (icl_group_create allows repeated devices for exactly this) and the 2-process
+test shares the GPU and stages spans through host memory (gloo); the peer-copy / RCCL transports differ only in the copy."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import ward_cases as WC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from imageclust_amd import _lib
+
+    return _lib
+
+
+def test_group_embed_and_cluster_equal_single_gpu(L):
+    ctx = L.Context(0)
+    ctx.load_synthetic(1)
+    imgs = L.synth_images(20250217, 0, 37, L.SYNTH_STRUCTURED)  # ragged over 3 contexts: 13 + 12 + 12
+    want32 = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32)
+    want16 = ctx.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_BF16)
+    g = L.Group([0, 0, 0])
+    try:
+        assert g.size() == 3
+        g.load_synthetic(1)
+        assert np.array_equal(g.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32), want32)
+        assert np.array_equal(g.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_BF16), want16)
+        for (E, mn, mx) in [(WC.mog(1500, 32, 3), 5, 50), (WC.ties(1100, 4, 2, levels=5), 2, 9), (WC.mog(900, 2048, 4), 3, 6)]:
+            cid, rank, nc = g.cluster(E, mn, mx)
+            c1, r1, n1 = ctx.cluster(E, mn, mx)
+            assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1)
+            f = O.cluster_fast(E, mn, mx, lazy_ban=False)
+            assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"])
+        # inputs too small to deal out, constraint errors and FAST mode take the single-GPU path with the same contract
+        cid, rank, nc = g.cluster(WC.mog(64, 8, 1), 3, 6)
+        r = O.cluster(WC.mog(64, 8, 1), 3, 6)
+        assert np.array_equal(cid, r["cluster_id"]) and nc == r["n_clusters"]
+        with pytest.raises(L.ICLError) as ei:
+            g.cluster(np.zeros((10, 1), np.float32), 4, 4)
+        assert ei.value.code == L.ICL_ERR_CONSTRAINT
+    finally:
+        g.close()
+        ctx.close()
+
+
+def test_distance_row_spans_are_the_rows_of_the_matrix(L):
+    import torch
+
+    ctx = L.Context(0)
+    try:
+        n, d = 700, 48
+        E = WC.mog(n, d, 9)
+        full = ctx.ward_distance_matrix(E)
+        dE = torch.from_numpy(E).cuda()
+        for parts in (1, 2, 3, 5):
+            got = []
+            for p in range(parts):
+                lo, hi = L.ward_rows_partition(n, parts, p)
+                off, cnt = L.ward_span(lo, hi)
+                span = torch.full((max(cnt, 1),), -1.0, device="cuda")
+                if cnt:
+                    ctx.ward_distance_rows_dev(dE.data_ptr(), n, d, lo, hi, span.data_ptr())
+                got.append(span[:cnt].cpu().numpy())
+            tri = np.concatenate(got)
+            pos = 0
+            for r in range(n):
+                assert np.array_equal(tri[pos:pos + r].view(np.uint32), full[r, :r].view(np.uint32)), (parts, r)
+                pos += (r + 3) // 4 * 4
+        # engine-owned triangle memory addressed from torch without a copy (what an RCCL recv writes into)
+        from imageclust_amd import distributed as D
+
+        ctx.ward_prepare(n, d)
+        ptr, cnt = ctx.ward_span_ptr(128, 384)
+        t = torch.as_tensor(D._DeviceSpan(ptr, cnt), device="cuda")
+        assert t.numel() == cnt == L.ward_span(128, 384)[1] and t.data_ptr() == ptr
+        t.fill_(3.5)
+        torch.cuda.synchronize()
+        back = np.zeros(4, np.float32)
+        ctx.d2h(back, ptr + (cnt - 4) * 4)
+        assert (back == 3.5).all()
+    finally:
+        ctx.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+
+    from imageclust_amd import _lib
+    from imageclust_amd import distributed as D
+
+    D.init("gloo", rank, world)
+    ctx = _lib.Context(0)  # both ranks share the box's one GPU
+    E = WC.mog(1300, 64, 21)
+    dE = torch.from_numpy(E).cuda()
+    res = D.cluster_with_distributed_tiles(ctx, dE, 5, 50, rank, world, staged=True)
+    out = None
+    if rank == 0:
+        cid, mr, nc = res
+        c1, r1, n1 = ctx.cluster(E, 5, 50)
+        out = bool(nc == n1 and np.array_equal(cid, c1) and np.array_equal(mr, r1))
+    D.barrier()
+    q.put((rank, out))
+    ctx.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_distributed_tiles_equal_single_gpu():
+    """bench.py's N>1 control flow on one GPU: 2 processes, each computes its run of distance rows, rank 0 assembles the
+    triangle and clusters; ids must equal the single-GPU run."""
+    import torch.multiprocessing as mp
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0] is True
