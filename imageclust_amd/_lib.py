@@ -38,6 +38,7 @@ SYMBOLS = [
     ("icl_memcpy_h2d", _int, [_vp, _vp, _vp, _i64]),
     ("icl_memcpy_d2h", _int, [_vp, _vp, _vp, _i64]),
     ("icl_model_load_onnx", _int, [_vp, C.c_char_p]),
+    ("icl_onnx_to_blob_file", _int, [C.c_char_p, _vp, _i64, _pi64]),
     ("icl_model_load_blob", _int, [_vp, _vp, _i64]),
     ("icl_model_load_synthetic", _int, [_vp, C.c_uint64]),
     ("icl_synthetic_blob_bytes", _i64, []),
@@ -462,6 +463,20 @@ def decode_image_file(path):
         raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
     out = np.empty((h.value, w.value, 3), np.uint8)
     rc = L.icl_decode_image_file(os.fsencode(path), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h))
+    if rc:
+        raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
+    return out
+
+
+def onnx_to_blob(path):
+    """The ONNX reader's conversion alone (host only): file -> ICLW blob as a uint8 array."""
+    L = load()
+    n = _i64()
+    rc = L.icl_onnx_to_blob_file(os.fsencode(path), None, 0, C.byref(n))
+    if rc:
+        raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
+    out = np.empty(n.value, np.uint8)
+    rc = L.icl_onnx_to_blob_file(os.fsencode(path), out.ctypes.data, out.nbytes, C.byref(n))
     if rc:
         raise ICLError(rc, (L.icl_last_error(None) or b"").decode())
     return out

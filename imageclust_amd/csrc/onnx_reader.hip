@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -277,19 +278,99 @@ static int onnx_to_blob_impl(icl_ctx *ctx, const char *path, std::vector<char> &
         }
         if (!r.ok) return icl_fail(ctx, ICL_ERR_IO, "%s: malformed GraphProto", path);
     }
-    // consumer lookup: tensor name -> BatchNormalization node that reads it
+    // The graph is WALKED by data flow (producer -> consumer), never trusted to list its nodes in any particular order:
+    // stem Conv -> BN -> Relu -> MaxPool -> 16 bottleneck blocks { x -> c1 1x1 -> BN -> Relu -> c2 3x3 -> BN -> Relu -> c3 1x1
+    // -> BN ; [x -> downsample 1x1 -> BN] ; Add ; Relu } -> GlobalAveragePool -> Flatten/Reshape -> Gemm.  The convolutions
+    // come out in the blob's order (c1, c2, c3, downsample per block), whatever order the exporter wrote them in.
     std::map<std::string, const onnx_node *> bn_of;
+    std::multimap<std::string, const onnx_node *> cons; // tensor -> nodes that read it as DATA (not as a parameter)
+    std::set<std::string> produced;
     const onnx_node *gemm = nullptr;
-    std::vector<const onnx_node *> convs;
+    size_t n_conv_nodes = 0;
     for (const auto &n : nodes) {
+        for (const auto &o : n.out) produced.insert(o);
+        if (n.op == "Conv") ++n_conv_nodes;
+        if (n.op == "Gemm") gemm = &n;
         if (n.op == "BatchNormalization" && n.in.size() >= 5) bn_of[n.in[0]] = &n;
-        else if (n.op == "Conv") convs.push_back(&n);
-        else if (n.op == "Gemm") gemm = &n;
+        const size_t ndata = n.op == "Add" ? std::min<size_t>(2, n.in.size()) : std::min<size_t>(1, n.in.size());
+        for (size_t q = 0; q < ndata; ++q) cons.insert({n.in[q], &n});
     }
     icl_conv_rec topo[ICL_RESNET50_NCONV];
     const int nconv = resnet50_topology_onnx(topo);
-    if ((int)convs.size() != nconv || !gemm)
-        return icl_fail(ctx, ICL_ERR_IO, "%s: expected a ResNet50-v1 graph (53 Conv + 1 Gemm), found %zu Conv%s", path, convs.size(), gemm ? "" : ", no Gemm");
+    if ((int)n_conv_nodes != nconv || !gemm)
+        return icl_fail(ctx, ICL_ERR_IO, "%s: expected a ResNet50-v1 graph (53 Conv + 1 Gemm), found %zu Conv%s", path, n_conv_nodes, gemm ? "" : ", no Gemm");
+    auto readers = [&](const std::string &t, const char *op) {
+        std::vector<const onnx_node *> r;
+        auto range = cons.equal_range(t);
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second->op == op) r.push_back(it->second);
+        return r;
+    };
+    auto only = [&](const std::string &t, const char *op) -> const onnx_node * {
+        auto r = readers(t, op);
+        return (r.size() == 1 && !r[0]->out.empty()) ? r[0] : nullptr;
+    };
+    auto cout_of = [&](const onnx_node *c) -> int64_t {
+        if (c->in.size() < 2) return -1;
+        auto it = init.find(c->in[1]);
+        return (it == init.end() || it->second.dims.size() != 4) ? -1 : it->second.dims[0];
+    };
+    auto walk_fail = [&](int idx, const char *what) {
+        return icl_fail(ctx, ICL_ERR_IO, "%s: not a ResNet50-v1 graph: conv %d: %s", path, idx, what);
+    };
+    std::vector<const onnx_node *> convs;
+    std::string x;
+    { // stem: the Conv whose data input no node produces (the graph input)
+        const onnx_node *stem = nullptr;
+        for (const auto &n : nodes)
+            if (n.op == "Conv" && !n.in.empty() && !produced.count(n.in[0]) && !init.count(n.in[0])) stem = stem ? nullptr : &n;
+        if (!stem || stem->out.empty()) return walk_fail(0, "no unique convolution reads the graph input");
+        convs.push_back(stem);
+        const onnx_node *bn = only(stem->out[0], "BatchNormalization");
+        const onnx_node *re = bn ? only(bn->out[0], "Relu") : nullptr;
+        const onnx_node *mp = re ? only(re->out[0], "MaxPool") : nullptr;
+        if (!mp) return walk_fail(0, "expected Conv -> BatchNormalization -> Relu -> MaxPool");
+        x = mp->out[0];
+    }
+    for (int i = 1; i < nconv;) {
+        const bool has_ds = i + 3 < nconv && topo[i + 3].role == 4; // the blob's order: c1, c2, c3, then the block's downsample if it has one
+        auto cs = readers(x, "Conv");
+        const onnx_node *c1 = nullptr, *ds = nullptr;
+        for (const onnx_node *c : cs) {
+            if (cout_of(c) == topo[i].cout && !c1) c1 = c;
+            else if (has_ds && cout_of(c) == topo[i + 3].cout && !ds) ds = c;
+            else return walk_fail(i, "unexpected convolution on the block input");
+        }
+        if (!c1 || (has_ds && !ds) || c1->out.empty()) return walk_fail(i, "block input does not feed the expected 1x1 convolution(s)");
+        const onnx_node *b1 = only(c1->out[0], "BatchNormalization"), *r1 = b1 ? only(b1->out[0], "Relu") : nullptr;
+        const onnx_node *c2 = r1 ? only(r1->out[0], "Conv") : nullptr;
+        const onnx_node *b2 = c2 ? only(c2->out[0], "BatchNormalization") : nullptr, *r2 = b2 ? only(b2->out[0], "Relu") : nullptr;
+        const onnx_node *c3 = r2 ? only(r2->out[0], "Conv") : nullptr;
+        const onnx_node *b3 = c3 ? only(c3->out[0], "BatchNormalization") : nullptr;
+        const onnx_node *add = b3 ? only(b3->out[0], "Add") : nullptr;
+        if (!add) return walk_fail(i, "expected 1x1 -> BN -> Relu -> 3x3 -> BN -> Relu -> 1x1 -> BN -> Add");
+        const std::string &other = add->in[0] == b3->out[0] ? add->in[1] : add->in[0];
+        if (has_ds) {
+            const onnx_node *bd = ds->out.empty() ? nullptr : only(ds->out[0], "BatchNormalization");
+            if (!bd || bd->out[0] != other) return walk_fail(i + 3, "the downsample branch does not reach the block's Add");
+        } else if (other != x)
+            return walk_fail(i, "the identity branch does not reach the block's Add");
+        const onnx_node *ro = only(add->out[0], "Relu");
+        if (!ro) return walk_fail(i, "expected Add -> Relu");
+        convs.push_back(c1);
+        convs.push_back(c2);
+        convs.push_back(c3);
+        if (has_ds) convs.push_back(ds);
+        x = ro->out[0];
+        i += has_ds ? 4 : 3;
+    }
+    { // head: GlobalAveragePool -> (Flatten | Reshape) -> Gemm
+        const onnx_node *gp = only(x, "GlobalAveragePool");
+        const onnx_node *fl = gp ? only(gp->out[0], "Flatten") : nullptr;
+        if (gp && !fl) fl = only(gp->out[0], "Reshape");
+        if (!fl || gemm->in.empty() || gemm->in[0] != fl->out[0]) return walk_fail(nconv, "expected GlobalAveragePool -> Flatten -> Gemm after the last block");
+    }
+    if ((int)convs.size() != nconv) return walk_fail((int)convs.size(), "the walk did not visit every convolution");
 
     icl_blob_header h;
     memset(&h, 0, sizeof h);
@@ -352,5 +433,21 @@ static int onnx_to_blob_impl(icl_ctx *ctx, const char *path, std::vector<char> &
     blob.resize(sizeof h + payload.size() * 4);
     memcpy(blob.data(), &h, sizeof h);
     memcpy(blob.data() + sizeof h, payload.data(), payload.size() * 4);
+    return ICL_OK;
+}
+
+// The conversion alone, for hosts without a GPU: ONNX file -> ICLW blob bytes (include/icl_model_format.h).  With blob == NULL
+// only *bytes is returned.  tests/test_onnx_reader.py compares the blob's tensors with what an independent protobuf parser
+// finds in the same file.
+extern "C" int icl_onnx_to_blob_file(const char *path, void *blob, int64_t cap_bytes, int64_t *bytes)
+{
+    if (!path || !bytes) return icl_fail(nullptr, ICL_ERR_ARG, "icl_onnx_to_blob_file: bad argument");
+    std::vector<char> b;
+    ICL_TRY(icl_onnx_to_blob(nullptr, path, b));
+    *bytes = (int64_t)b.size();
+    if (blob) {
+        if (cap_bytes < (int64_t)b.size()) return icl_fail(nullptr, ICL_ERR_ARG, "icl_onnx_to_blob_file: buffer too small");
+        memcpy(blob, b.data(), b.size());
+    }
     return ICL_OK;
 }

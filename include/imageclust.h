@@ -63,6 +63,8 @@ int icl_memcpy_d2h(icl_ctx *ctx, void *dst_host, const void *src_dev, int64_t by
 /* ---- model: replaces LoadPretrainedModelONNX (internal/embeddings/embeddings.go:28-43) ------------------- */
 /* Parse an ONNX file's initializers (no protobuf dependency) into the context. */
 int icl_model_load_onnx(icl_ctx *ctx, const char *path);
+/* The conversion step of the above alone (host only, no GPU): ONNX file -> ICLW blob; blob == NULL returns the size. */
+int icl_onnx_to_blob_file(const char *path, void *blob, int64_t cap_bytes, int64_t *bytes);
 /* Load an "ICLW" blob (include/icl_model_format.h). */
 int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes);
 /* Seeded synthetic ResNet50-v1 weights: generate on the host, then load. */

@@ -61,6 +61,61 @@ def node(op, ins, outs, attrs=()):
     return b
 
 
+def _fields(buf):
+    """(field number, wire type, value bytes / int) of one message level -- just enough to re-order NodeProtos."""
+    i = 0
+    while i < len(buf):
+        key = 0
+        sh = 0
+        while True:
+            b = buf[i]
+            i += 1
+            key |= (b & 0x7F) << sh
+            sh += 7
+            if not b & 0x80:
+                break
+        num, wt = key >> 3, key & 7
+        if wt == 2:
+            ln = 0
+            sh = 0
+            while True:
+                b = buf[i]
+                i += 1
+                ln |= (b & 0x7F) << sh
+                sh += 7
+                if not b & 0x80:
+                    break
+            yield num, wt, bytes(buf[i:i + ln])
+            i += ln
+        elif wt == 0:
+            while buf[i] & 0x80:
+                i += 1
+            i += 1
+            yield num, wt, None
+        elif wt == 5:
+            i += 4
+            yield num, wt, None
+        else:
+            raise ValueError("wire type %d" % wt)
+
+
+def _random_topological_order(nodes, rng):
+    ins, outs = [], []
+    for nb in nodes:
+        f = list(_fields(nb))
+        ins.append([v.decode() for n, w, v in f if n == 1])
+        outs.append([v.decode() for n, w, v in f if n == 2])
+    produced_by = {o: k for k, os_ in enumerate(outs) for o in os_}
+    deps = [{produced_by[i] for i in ins[k] if i in produced_by} for k in range(len(nodes))]
+    done, order = set(), []
+    while len(order) < len(nodes):
+        ready = [k for k in range(len(nodes)) if k not in done and deps[k] <= done]
+        k = ready[int(rng.integers(len(ready)))]
+        done.add(k)
+        order.append(nodes[k])
+    return order
+
+
 def topology():
     t = [(3, 64, 7, 2, 3, 0, 0)]
     cin = 64
@@ -75,7 +130,11 @@ def topology():
     return t
 
 
-def blob_to_onnx(blob: np.ndarray, path: str, raw=True, trans_b=1):
+def blob_to_onnx(blob: np.ndarray, path: str, raw=True, trans_b=1, gluon_names=False, ds_first=False, shuffle=None, reshape_head=False):
+    """gluon_names: Gluon-style initializer names (stageN_convK / stageN_batchnormK) instead of one running conv index;
+    ds_first: every block lists its downsample Conv/BN BEFORE the main branch (a different, equally valid topological order);
+    shuffle: a numpy Generator -- initializers in random order, nodes in a random TOPOLOGICAL order; reshape_head: Reshape
+    instead of Flatten in front of the Gemm.  The loader must find every tensor by walking the graph, not by position."""
     hdr = blob[:80]
     eps = float(np.frombuffer(hdr[8:12].tobytes(), np.float32)[0])
     has_bias = hdr[16:80]
@@ -90,8 +149,17 @@ def blob_to_onnx(blob: np.ndarray, path: str, raw=True, trans_b=1):
         pos += n
         return v
 
-    def conv_bn(i, x, cin, cout, k, s, pad):
-        names = ["resnetv17_conv%d_%s" % (i, q) for q in ("weight", "bias", "gamma", "beta", "running_mean", "running_var")]
+    gl = {"stage": 0, "conv": 0, "bn": 0}
+
+    def conv_bn(i, x, cin, cout, k, s, pad, out_nodes=None):
+        out_nodes = nodes if out_nodes is None else out_nodes
+        if gluon_names:
+            pre = "resnetv17_" if gl["stage"] == 0 else "resnetv17_stage%d_" % gl["stage"]
+            names = [pre + "conv%d_weight" % gl["conv"], pre + "conv%d_bias" % gl["conv"]] + [pre + "batchnorm%d_%s" % (gl["bn"], q) for q in ("gamma", "beta", "running_mean", "running_var")]
+            gl["conv"] += 1
+            gl["bn"] += 1
+        else:
+            names = ["resnetv17_conv%d_%s" % (i, q) for q in ("weight", "bias", "gamma", "beta", "running_mean", "running_var")]
         inits.append(tensor(names[0], take((cout, cin, k, k)), raw, packed_dims=(i % 2 == 0)))
         ins = [x, names[0]]
         if has_bias[i]:
@@ -100,9 +168,9 @@ def blob_to_onnx(blob: np.ndarray, path: str, raw=True, trans_b=1):
         for q in range(2, 6):
             inits.append(tensor(names[q], take((cout,)), raw))
         y, z = "conv%d_fwd" % i, "bn%d_fwd" % i
-        nodes.append(node("Conv", ins, [y], [attr_ints("dilations", [1, 1]), attr_int("group", 1), attr_ints("kernel_shape", [k, k]),
-                                             attr_ints("pads", [pad] * 4), attr_ints("strides", [s, s])]))
-        nodes.append(node("BatchNormalization", [y] + names[2:6], [z], [attr_float("epsilon", eps), attr_float("momentum", 0.9)]))
+        out_nodes.append(node("Conv", ins, [y], [attr_ints("dilations", [1, 1]), attr_int("group", 1), attr_ints("kernel_shape", [k, k]),
+                                                 attr_ints("pads", [pad] * 4), attr_ints("strides", [s, s])]))
+        out_nodes.append(node("BatchNormalization", [y] + names[2:6], [z], [attr_float("epsilon", eps), attr_float("momentum", 0.9)]))
         return z
 
     def relu(x, tag):
@@ -116,21 +184,35 @@ def blob_to_onnx(blob: np.ndarray, path: str, raw=True, trans_b=1):
     i = 1
     while i < len(topo):
         has_ds = topo[i][6] == 0
+        if has_ds:
+            gl["stage"] += 1
+            gl["conv"] = gl["bn"] = 0
+        at = len(nodes)
         t = relu(conv_bn(i, x, *topo[i][:5]), "r%da" % i)
         t = relu(conv_bn(i + 1, t, *topo[i + 1][:5]), "r%db" % i)
         t = conv_bn(i + 2, t, *topo[i + 2][:5])
-        res = conv_bn(i + 3, x, *topo[i + 3][:5]) if has_ds else x
-        nodes.append(node("Add", [t, res], ["add%d" % i]))
+        if has_ds:  # the blob stores the downsample tensors AFTER the block's c3 either way; only the node order changes
+            ds_nodes = []
+            res = conv_bn(i + 3, x, *topo[i + 3][:5], out_nodes=ds_nodes)
+            nodes[at:at] = ds_nodes if ds_first else []
+            if not ds_first:
+                nodes.extend(ds_nodes)
+        else:
+            res = x
+        nodes.append(node("Add", [res, t] if ds_first else [t, res], ["add%d" % i]))
         x = relu("add%d" % i, "out%d" % i)
         i += 4 if has_ds else 3
     nodes.append(node("GlobalAveragePool", [x], ["pool1"]))
-    nodes.append(node("Flatten", ["pool1"], ["flat"]))
+    nodes.append(node("Reshape" if reshape_head else "Flatten", ["pool1"], ["flat"]))
     W = take((1000, 2048))
     inits.append(tensor("resnetv17_dense0_weight", W if trans_b else np.ascontiguousarray(W.T), raw))
     inits.append(tensor("resnetv17_dense0_bias", take((1000,)), raw))
     nodes.append(node("Gemm", ["flat", "resnetv17_dense0_weight", "resnetv17_dense0_bias"], ["resnetv17_dense0_fwd"],
                       [attr_float("alpha", 1.0), attr_float("beta", 1.0), attr_int("transA", 0), attr_int("transB", trans_b)]))
     assert pos == len(p)
+    if shuffle is not None:
+        inits = [inits[k] for k in shuffle.permutation(len(inits))]
+        nodes = _random_topological_order(nodes, shuffle)
     graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"mxnet_converted_model") + b"".join(_ld(5, t) for t in inits)
     model = _vi(1, 3) + _ld(2, b"onnx-mxnet") + _ld(7, graph) + _ld(8, _ld(1, b"") + _vi(2, 7))
     with open(path, "wb") as f:
