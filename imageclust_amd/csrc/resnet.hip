@@ -1098,14 +1098,29 @@ static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int h
         ICL_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int l = 1; l < lanes; ++l) ICL_HIP(ctx, hipStreamWaitEvent(lane_stream(l), ctx->ev_fork, 0));
     }
+    // At most DEPTH batches (DEPTH x 55 launches) are enqueued ahead of the GPU: the host waits for batch bi-DEPTH before it
+    // enqueues batch bi.  The queues never run dry (hundreds of launches deep), and the number of dispatches in flight stays
+    // bounded however many images a call embeds -- unbounded, a 100 000-image call had 21 500 launches outstanding, which
+    // `rocprofv3 --pmc` does not survive (SIGSEGV in the tool once several thousand counter-instrumented dispatches are pending;
+    // 2 200 are fine, 8 600 are not: profiles/README.md).
+    constexpr int DEPTH = 16;
+    hipEvent_t ring[DEPTH] = {};
+    struct ring_guard {
+        hipEvent_t *r;
+        ~ring_guard() { for (int q = 0; q < DEPTH; ++q) if (r[q]) (void)hipEventDestroy(r[q]); }
+    } rg{ring};
     int64_t bi = 0;
     for (int64_t i = 0; i < n; i += batch, ++bi) {
         const int B = (int)std::min<int64_t>(batch, n - i);
         const int lane = (int)(bi % lanes);
         hipStream_t strm = lane_stream(lane);
+        hipEvent_t &ev = ring[bi % DEPTH];
+        if (ev) ICL_HIP(ctx, hipEventSynchronize(ev)); // batch bi-DEPTH has finished
+        else ICL_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         const int rc = prec == ICL_PREC_BF16 ? forward_batch<BF16>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm)
                                              : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm);
         if (rc) return rc;
+        ICL_HIP(ctx, hipEventRecord(ev, strm));
     }
     ctx->cur_stream = nullptr;
     for (int l = 1; l < lanes; ++l) { // join

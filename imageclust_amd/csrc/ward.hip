@@ -90,6 +90,7 @@ struct icl_ward_ws {
     float *CT = nullptr;       // [D][S] centroids, transposed: slot-contiguous
     float *Crow = nullptr;     // [S][D] the same centroids, cluster-contiguous (coalesced merge of two centroids)
     float *cnew = nullptr;     // [WB_K][cn_stride] centroids of the clusters created by the current step (batched: up to WB_K)
+    float *cnewI = nullptr;    // [WB_K/2][cn_stride][2] the same, chains 2p and 2p+1 interleaved (ward_interleave_kernel)
     int64_t cn_stride = 0;     // floats per centroid image (zero padded)
     int32_t *slot_id = nullptr;// [S] creation id held by a slot, -1 if free
     int32_t *id_slot = nullptr;// [M]
@@ -120,7 +121,7 @@ void icl_ward_free(icl_ctx *ctx)
     ctx->ward_rowoff_n = 0;
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
-    void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+    void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
                     w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out};
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
@@ -1748,9 +1749,22 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 static_assert(WB_SG == 16 && WB_SG % WX_L == 0, "a stage is 16 k-groups, dealt evenly to the loader waves");
 static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
 
+// The new centroids of chains 2p and 2p+1, interleaved element by element: cnewI[p][k] = {c_2p[k], c_2p+1[k]}.  A chain wave
+// runs both chains of its pair with PACKED fp32 ops ({x[k], x[k]} - {cA[k], cB[k]}, squared, added to {sA, sB}: 3 v_pk
+// instructions per k for two chains instead of 4 -- the update kernel is VALU-issue bound), which needs cA[k] and cB[k] in
+// one register pair.  Runs after every finish kernel (which writes cnewK), 128 KB.
+__global__ void ward_interleave_kernel(const float *__restrict__ cnewK, int64_t cn_stride, float *__restrict__ cnewI)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (pair, k)
+    const int64_t p = i / cn_stride, k = i % cn_stride;
+    if (p >= WB_K / 2) return;
+    const float2 v = make_float2(cnewK[(2 * p) * cn_stride + k], cnewK[(2 * p + 1) * cn_stride + k]);
+    reinterpret_cast<float2 *>(cnewI)[p * cn_stride + k] = v;
+}
+
 __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
-                                                                      int64_t cn_stride,
+                                                                      const float *__restrict__ cnewI, int64_t cn_stride,
                                                                       const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
                                                                       const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
@@ -1857,8 +1871,11 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
     const int64_t row_bytes = virt ? 16 : S * 16;
     const unsigned ring_base = lds_addr_of(wb_lds);
-    // lane l of loader pj fetches k-group (stage*16 + l%16) of chain 4*(piece) + l/16 for its centroid piece(s)
-    const char *csrc = reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * WX_COPS * (pj & (WX_L - 1)) + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
+    // centroid pieces.  WX_CPW == 2: the ring holds [pair][k-group][2] float4 = {cA[4g+2h], cB[4g+2h], cA[4g+2h+1], cB[4g+2h+1]} from the
+    // interleaved copy: lane l of piece q fetches pair 2q + l/32, k-group (l%32)/2, half l%2.  WX_CPW == 1: [chain][k-group] from cnewK.
+    const int64_t pc0 = WX_COPS * (pj & (WX_L - 1));
+    const char *csrc = WX_CPW == 2 ? reinterpret_cast<const char *>(cnewI) + ((int64_t)(2 * pc0 + (lane >> 5)) * 2 * cn_stride + (int64_t)((lane & 31) >> 1) * 8 + (lane & 1) * 4) * 4
+                                   : reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * pc0 + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
     auto issue = [&](int stage) { // this loader wave's pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
         const int g0 = stage * WB_SG + pj * WX_XOPS;
         const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
@@ -1876,7 +1893,8 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         }
 #pragma unroll
         for (int q = 0; q < WX_COPS; ++q)
-            glds16_asm(csrc + (int64_t)q * 4 * cn_stride * 4 + (int64_t)stage * (WB_SG * 16), sbase + (unsigned)(WX_NS * WB_SG * 1024 + (pj * WX_COPS + q) * 1024));
+            glds16_asm(csrc + (int64_t)q * 4 * cn_stride * 4 + (int64_t)stage * (WB_SG * (WX_CPW == 2 ? 32 : 16)),
+                       sbase + (unsigned)(WX_NS * WB_SG * 1024 + (pj * WX_COPS + q) * 1024));
     };
     const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
     const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
@@ -1889,6 +1907,10 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) sA[u] = sB[u] = 0.0f;
     // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
+    f2 sP[WX_NS]; // WX_CPW == 2: {sA, sB} of each slot set as one packed register pair
+#pragma unroll
+    for (int u = 0; u < WX_NS; ++u) sP[u] = f2{0.0f, 0.0f};
+    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
     auto quarter = [&](const float4 *xr, const float4 *ca, const float4 *cb, auto nsets_tag) {
         constexpr int NSETS = decltype(nsets_tag)::value;
         float4 xv[NSETS][4], c0[4], c1[4];
@@ -1896,47 +1918,56 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
             for (int u = 0; u < NSETS; ++u) xv[u][g] = xr[(u * WB_SG + g) * 64];
-            c0[g] = ca[g];
-            if (WX_CPW == 2) c1[g] = cb[g];
+            if (WX_CPW == 2) {
+                c0[g] = ca[2 * g];     // {cA[4g], cB[4g], cA[4g+1], cB[4g+1]}
+                c1[g] = ca[2 * g + 1]; // {cA[4g+2], cB[4g+2], cA[4g+3], cB[4g+3]}
+            } else {
+                c0[g] = ca[g];
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f2 qa[NSETS], qb[NSETS], ra[NSETS], rb[NSETS];
+            if (WX_CPW == 2) {
+                // both chains of the pair in the two halves of packed fp32 ops: {x[k], x[k]} - {cA[k], cB[k]} (clustering.go:139 via
+                // :84), squared (:154 product), added to {sA, sB} (:154 sum) -- each half is rounded exactly like the scalar op, and
+                // each running sum still takes its terms strictly in k order
+                const f2 k0 = {c0[g].x, c0[g].y}, k1 = {c0[g].z, c0[g].w}, k2 = {c1[g].x, c1[g].y}, k3 = {c1[g].z, c1[g].w};
 #pragma unroll
-            for (int u = 0; u < NSETS; ++u) {
-                const f2 xa = {xv[u][g].x, xv[u][g].y}, xb = {xv[u][g].z, xv[u][g].w};
-                const f2 a0 = {c0[g].x, c0[g].y}, a1 = {c0[g].z, c0[g].w};
-                const f2 da = xa - a0, db = xb - a1; // clustering.go:139 via :84
-                qa[u] = da * da;                     // :154 products, each rounded
-                qb[u] = db * db;
-                if (WX_CPW == 2) {
-                    const f2 b0 = {c1[g].x, c1[g].y}, b1 = {c1[g].z, c1[g].w};
-                    const f2 ea = xa - b0, eb = xb - b1;
-                    ra[u] = ea * ea;
-                    rb[u] = eb * eb;
+                for (int u = 0; u < NSETS; ++u) {
+                    const f2 x0 = {xv[u][g].x, xv[u][g].x}, x1 = {xv[u][g].y, xv[u][g].y}, x2 = {xv[u][g].z, xv[u][g].z}, x3 = {xv[u][g].w, xv[u][g].w};
+                    const f2 d0 = x0 - k0, d1 = x1 - k1, d2 = x2 - k2, d3 = x3 - k3;
+                    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+                    sP[u] = sP[u] + q0;
+                    sP[u] = sP[u] + q1;
+                    sP[u] = sP[u] + q2;
+                    sP[u] = sP[u] + q3;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NSETS; ++u) {
+                    const f2 xa = {xv[u][g].x, xv[u][g].y}, xb = {xv[u][g].z, xv[u][g].w};
+                    const f2 a0 = {c0[g].x, c0[g].y}, a1 = {c0[g].z, c0[g].w};
+                    const f2 da = xa - a0, db = xb - a1; // clustering.go:139 via :84
+                    const f2 qa = da * da, qb = db * db; // :154 products, each rounded
+                    sA[u] = sA[u] + qa.x;                // :154 the running sum, strictly in k order
+                    sA[u] = sA[u] + qa.y;
+                    sA[u] = sA[u] + qb.x;
+                    sA[u] = sA[u] + qb.y;
                 }
             }
-            // :154 the running sums, each strictly in k order; the independent sums alternate so that no add waits for the
-            // one just issued
-#pragma unroll
-            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qa[u].x; if (WX_CPW == 2) sB[u] = sB[u] + ra[u].x; }
-#pragma unroll
-            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qa[u].y; if (WX_CPW == 2) sB[u] = sB[u] + ra[u].y; }
-#pragma unroll
-            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qb[u].x; if (WX_CPW == 2) sB[u] = sB[u] + rb[u].x; }
-#pragma unroll
-            for (int u = 0; u < NSETS; ++u) { sA[u] = sA[u] + qb[u].y; if (WX_CPW == 2) sB[u] = sB[u] + rb[u].y; }
         }
     };
     auto consume = [&](int stage) {
         const float4 *sb_ = wb_lds + (stage % WX_R) * WX_STAGE_F4;
         const float4 *xr = sb_ + lane;
-        const float4 *ca = sb_ + WX_NS * WB_SG * 64 + jA * WB_SG; // wave-uniform: broadcast reads
-        const float4 *cb = sb_ + WX_NS * WB_SG * 64 + jB * WB_SG;
+        // wave-uniform addresses: broadcast reads.  WX_CPW == 2: this wave's pair, [k-group][2 halves]; else [chain][k-group]
+        const float4 *ca = sb_ + WX_NS * WB_SG * 64 + (WX_CPW == 2 ? (jA >> 1) * (2 * WB_SG) : jA * WB_SG);
+        const float4 *cb = ca;
 #pragma unroll
         for (int q = 0; q < WB_SG / 4; ++q) {
-            if (two) quarter(xr + q * 4 * 64, ca + q * 4, cb + q * 4, std::integral_constant<int, WX_NS>());
-            else quarter(xr + q * 4 * 64, ca + q * 4, cb + q * 4, std::integral_constant<int, 1>());
+            const float4 *cq = ca + q * 4 * (WX_CPW == 2 ? 2 : 1);
+            if (two) quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, WX_NS>());
+            else quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, 1>());
         }
     };
     for (int i = 0; i < nstage; ++i) {
@@ -1984,7 +2015,7 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         unsigned long long key = ~0ull, key2 = ~0ull;
 #pragma unroll
         for (int u = 0; u < WX_NS; ++u) {
-            const float s = cc ? sB[u] : sA[u];
+            const float s = WX_CPW == 2 ? (cc ? sP[u].y : sP[u].x) : sA[u];
             if ((okmask[u] >> j) & 1u) {
                 const float num = (float)((int64_t)sx[u] * (int64_t)sc);
                 const float den = (float)(sx[u] + sc);
@@ -2877,13 +2908,13 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     icl_ward_ws *w = ctx->ward;
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
-        void *ptrs[] = {w->CT, w->Crow, w->cnew, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
+        void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
                         w->merges, w->st};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
         w->graph_exec = nullptr;
-        w->CT = w->Crow = w->cnew = w->rowmin = w->Dtri = nullptr;
+        w->CT = w->Crow = w->cnew = w->cnewI = w->rowmin = w->Dtri = nullptr;
         w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = nullptr;
         w->rowoff = nullptr;
         w->st = nullptr;
@@ -2914,6 +2945,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         w->cn_stride = 4 * std::max<int64_t>(ngrp, wb_groups((int)dd) + WB_PAD_G);
         WS_ALLOC(cnew, float, 16 * w->cn_stride); // 16 images whatever WB_K is: the update kernel's centroid pieces always cover 16 chains
         ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
+        WS_ALLOC(cnewI, float, 16 * w->cn_stride);
+        ICL_HIP(ctx, hipMemsetAsync(w->cnewI, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
         WS_ALLOC(slot_id, int32_t, w->S);
         WS_ALLOC(id_slot, int32_t, w->M);
         WS_ALLOC(asz, int32_t, w->M);
@@ -3287,6 +3320,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0);
+            if (!lw && gen2 && WX_CPW == 2) // the pair-interleaved copy of the centroids the finish kernel has just written
+                hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
+                                   w->cn_stride, w->cnewI);
         };
         auto update_b = [&]() {
             if (lw) {
@@ -3296,7 +3332,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
             if (gen2)
                 hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
-                                   w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag);
+                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag);
             else
                 hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                    w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
