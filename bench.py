@@ -266,21 +266,23 @@ def main():
         avg_us = c128["ms"] * 1e3 / max(c128["launches"], 1)
         achieved = c128["flops"] / max(c128["ms"], 1e-9) / 1e9  # TFLOP/s
         name, ncu, hbm = ctx.device_info()
-        # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
-        # two separate rocprofv3 --pmc passes of `bench.py --embed-only`); committed under profiles/ because bench.py
-        # itself cannot run under the profiler.
+        # HBM traffic of the same kernels from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, two
+        # separate `rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` passes:
+        # scratch/collect_profiles.sh).  The counters cannot be read while this run is being timed, so the per-launch means are
+        # committed under profiles/ and quoted here.
         traffic = traffic_upd = pmc_file = None
-        for pmc_file in ("r02_pmc_traffic.json", "r01_pmc_traffic_v2.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                    pmc = json.load(f)
-                traffic = round(pmc["conv_igemm_kernel<BF16,128>"]["hbm_bytes_per_launch"], 0)
-                traffic_upd = round(pmc["ward_update_batch_kernel"]["hbm_bytes_per_launch"], 0)
-                traffic_note = pmc.get("note_ward", "")
-                break
-            except Exception:
-                traffic_note = ""
-                continue
+        traffic_note = ""
+        try:  # profiles/r02_pmc_traffic.json: scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script at the default workload)
+            pmc_file = "r02_pmc_traffic.json"
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                pmc = json.load(f)
+            c_a, c_b = pmc["conv_igemm_kernel<BF16, 128, false, 2, true>"], pmc["conv_igemm_kernel<BF16, 128, true, 2, true>"]
+            traffic = round((c_a["hbm_bytes_per_launch"] * c_a["launches"] + c_b["hbm_bytes_per_launch"] * c_b["launches"])
+                            / (c_a["launches"] + c_b["launches"]), 0)
+            traffic_upd = round(pmc["ward_update_batch2_kernel"]["hbm_bytes_per_launch"], 0)
+            traffic_note = "(means over every launch of one bench.py run at N=100000; the ward figure includes the spare / preselection workgroups' row reads)"
+        except Exception:
+            pass
         conv_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                      "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
@@ -295,7 +297,8 @@ def main():
             ws = ctx.last_ward_stats()
             gbs = upd["bytes"] / max(upd["ms"], 1e-9) / 1e6  # GB/s
             exact = args.update == "exact"
-            ward_roof = {"bound": "hbm", "kernel": "ward_update_batch_kernel" if exact else "ward_update_lw_kernel",
+            tfl = upd["flops"] / max(upd["ms"], 1e-9) / 1e9  # 3 flop per (pair, k): sub, mul, add -- unfused by construction
+            ward_roof = {"bound": "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch_lw_kernel",
                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
                          "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note),
@@ -304,11 +307,15 @@ def main():
                          "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),
                          "merges_per_working_launch": round(ws["merges"] / max(ws["steps"], 1), 2),
                          "algorithmic_unit": "4*n_live*D bytes (one pass over the live centroids) + 4*n_live per new row, per LAUNCH; a launch "
-                                             "computes the rows of up to 8 independent merges from that one pass (SURVEY.md 8d quotes "
-                                             "4*n_live*D per merge)",
-                         "note": "at n_live >~ 30 000 one pass over the live centroids per launch is HBM-bound; below that the D "
-                                 "dependent fp32 adds of each in-order sum (one wave per merge row and 64 clusters) bound it; launches "
-                                 "after the last merge of a 64-step chunk are empty",
+                                             "computes the rows of up to 16 independent merges from that one pass (SURVEY.md 8d quotes "
+                                             "4*n_live*D per merge: 16x these bytes)",
+                         "valu": {"achieved": round(tfl, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_F32_TFLOPS, 4),
+                                  "note": "the exact update is 3 UNFUSED fp32 ops per (new row, live cluster, k) -- the reference's rounding "
+                                          "forbids FMA -- so half of the FMA-counted vector peak (78.6 TFLOP/s) is its ceiling; with 16 rows "
+                                          "per pass the kernel is bound by vector-ALU issue, not by HBM"},
+                         "note": "one workgroup per 64 live clusters streams their centroids once (LDS-DMA ring) and runs 16 in-order sums; "
+                                 "SURVEY.md 8d classifies the merge loop as HBM-bound, so the HBM fraction is reported as `frac`, the "
+                                 "vector-ALU fraction beside it; launches after the last merge of a 64-step chunk are empty",
                          "total_ms_in_profile_pass": round(upd["ms"], 1),
                          "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
                                      "(the timed steps replay a hipGraph)"}
