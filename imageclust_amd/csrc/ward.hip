@@ -61,6 +61,8 @@ struct ward_batch_state {
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
+    unsigned long long refined, pruned_waves, chain_waves, dirty_rows; // pruning statistics: entries made exact on demand; chain waves that stopped early / ran; new rows installed with a bound only
+    unsigned long long prune_hist[4][34]; // -DICL_WARD_TIMERS what-if: [beta index][stage a chain wave could stop at (32 = never), 33 = rows whose minimum exceeds tau]
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
     int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
     int32_t pa_rows[WB_R][WB_PA_CAP];              // rows of the slice whose cached partner is a member of the batch
@@ -470,6 +472,8 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
+        for (int j = 0; j < 4 * 34; ++j) (&st->B.prune_hist[0][0])[j] = 0;
+        st->B.refined = st->B.pruned_waves = st->B.chain_waves = st->B.dirty_rows = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
     }
 }
@@ -983,9 +987,169 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
     return k;
 }
 
-// scan_row with up to 2*WB_K excluded columns (the tentative batch's members)
-__device__ __forceinline__ void scan_row_ex(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
-                                            int max_size, const int *ex, int nex, float &bv, int &bi)
+// ---- partial-sum pruning (round 2) --------------------------------------------------------------------------------
+// The batched update kernel may stop a chain early: the in-order fp32 sum of squares only grows (every term is >= +0 and
+// rounded addition is monotone), so (size factor) x (partial sum) is a LOWER BOUND of the pair's final Ward value, bit-exactly,
+// without any error analysis.  Such an entry is stored NEGATED: v < 0 means "the true value is >= -v".  Every reader of a row
+// goes through scan_row_ex, which REFINES on demand: a flagged entry whose bound does not exceed the best exact value is
+// recomputed from the two committed centroids in the reference's order (clustering.go:136-157) and written back exact.
+struct wrefine {
+    const float *Crow;       // [slot][d] committed centroids
+    const int32_t *id_slot;  // creation id -> slot
+    int d;
+    int self_id;             // the row's own cluster
+    unsigned long long *stat; // refined entries (statistics), may be null
+};
+#define WB_REF_CAP 1024
+
+__device__ __forceinline__ float ward_exact_pair(const wrefine &rf, const int32_t *__restrict__ asz, int x)
+{
+    const float *a = rf.Crow + (int64_t)rf.id_slot[x] * rf.d, *b = rf.Crow + (int64_t)rf.id_slot[rf.self_id] * rf.d;
+    float s = 0.0f;
+    if ((rf.d & 3) == 0) {
+        for (int k = 0; k < rf.d; k += 4) {
+            const float4 av = *reinterpret_cast<const float4 *>(a + k), bv = *reinterpret_cast<const float4 *>(b + k);
+            float df = av.x - bv.x; // clustering.go:139
+            float p = df * df;      // :154 product
+            s = s + p;              // :154 sum, strictly in k order
+            df = av.y - bv.y;
+            p = df * df;
+            s = s + p;
+            df = av.z - bv.z;
+            p = df * df;
+            s = s + p;
+            df = av.w - bv.w;
+            p = df * df;
+            s = s + p;
+        }
+    } else {
+        for (int k = 0; k < rf.d; ++k) {
+            const float df = a[k] - b[k];
+            const float p = df * df;
+            s = s + p;
+        }
+    }
+    const int sx = asz[x], sc = asz[rf.self_id];
+    const float num = (float)((int64_t)sx * (int64_t)sc); // :142
+    const float den = (float)(sx + sc);                    // :143
+    return (num / den) * s;                                // :144
+}
+
+// scan_row with up to 2*WB_K excluded columns (the tentative batch's members).  Returns the row's first minimum over the live,
+// size-compatible, non-excluded columns.  With rf == nullptr the row must hold exact values only and the result is PER THREAD
+// (the caller reduces); with rf the result is already reduced over the workgroup (sv / si: scratch of 16 floats / ints) and
+// flagged entries are refined as needed.
+__device__ __noinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
+                                             int max_size, const int *ex, int nex, float &bv, int &bi, const wrefine *rf, float *sv, int *si)
+{
+    __shared__ int ref_cnt;
+    __shared__ int ref_col[WB_REF_CAP];
+    int e8[2 * WB_K];
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
+    const int64_t nvec = len >> 2; // packed rows start 16-byte aligned
+    // one pass over the row.  collect: append the flagged candidates whose bound is <= bound to ref_col; fv = smallest bound
+    // among the flagged candidates that were NOT appended
+    auto pass = [&](bool collect, float bound, float &tv, int &ti, float &fv) {
+        tv = ICL_MAXF;
+        ti = -1;
+        fv = ICL_MAXF;
+        auto visit = [&](float v, int m, int col) {
+            if (!(m > 0 && m + my_size <= max_size)) return;
+            if (v < 0.0f) { // flagged lower bound
+                bool ex_hit = false;
+#pragma unroll
+                for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
+                if (ex_hit) return;
+                const float lb = -v;
+                if (collect && lb <= bound) {
+                    const int at = atomicAdd(&ref_cnt, 1);
+                    if (at < WB_REF_CAP) {
+                        ref_col[at] = col;
+                        return;
+                    }
+                }
+                fv = lb < fv ? lb : fv;
+                return;
+            }
+            if (v < tv) {
+                bool ex_hit = false;
+#pragma unroll
+                for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
+                if (!ex_hit) {
+                    tv = v;
+                    ti = col;
+                }
+            }
+        };
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+            float4 v[4];
+            int4 m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const bool has = q < nvec;
+                v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                m[j] = has ? reinterpret_cast<const int4 *>(asz)[q] : make_int4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                const int mm[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) visit(vv[e], mm[e], (int)(q * 4 + e));
+            }
+        }
+        for (int64_t c = nvec * 4 + threadIdx.x; c < len; c += blockDim.x) visit(row[c], asz[c], (int)c);
+    };
+    float fv;
+    pass(false, 0.0f, bv, bi, fv);
+    if (!rf) return; // exact rows only (FAST mode, first-generation kernels): the caller reduces
+    block_argmin(bv, bi, sv, si);
+    {
+        int dummy = 0;
+        block_argmin(fv, dummy, sv, si);
+    }
+    while (fv < ICL_MAXF && fv <= bv) { // a flagged entry could win or tie: make those exact (fv == MaxFloat32: no flagged entry is left)
+        if (threadIdx.x == 0) ref_cnt = 0;
+        __syncthreads();
+        float tv, f2v;
+        int ti;
+        pass(true, bv, tv, ti, f2v);
+        __syncthreads();
+        const int m = ref_cnt < WB_REF_CAP ? ref_cnt : WB_REF_CAP;
+        float rv = ICL_MAXF;
+        int ri = -1;
+        if ((int)threadIdx.x < m) {
+            const int col = ref_col[threadIdx.x];
+            const float val = ward_exact_pair(*rf, asz, col);
+            row[col] = val; // exact from now on
+            if (val < ICL_MAXF) {
+                rv = val;
+                ri = col;
+            }
+        }
+        for (int q = (int)threadIdx.x + (int)blockDim.x; q < m; q += blockDim.x) { // workgroups smaller than the cap
+            const int col = ref_col[q];
+            const float val = ward_exact_pair(*rf, asz, col);
+            row[col] = val;
+            argmin_combine(rv, ri, val < ICL_MAXF ? val : ICL_MAXF, val < ICL_MAXF ? col : -1);
+        }
+        if (rf->stat && threadIdx.x == 0) atomicAdd(rf->stat, (unsigned long long)m);
+        block_argmin(rv, ri, sv, si);
+        argmin_combine(bv, bi, rv, ri);
+        int dummy = 0;
+        block_argmin(f2v, dummy, sv, si);
+        fv = f2v;
+        __syncthreads();
+    }
+}
+
+// The plain scan (exact rows only; the result is PER THREAD, the caller reduces): the hot path of the spare / preselection
+// workgroups.  The refining variant above is kept out of line so that its registers do not burden the update kernel.
+__device__ __forceinline__ void scan_row_plain(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
+                                               int max_size, const int *ex, int nex, float &bv, int &bi)
 {
     bv = ICL_MAXF;
     bi = -1;
@@ -1036,6 +1200,14 @@ __device__ __forceinline__ void scan_row_ex(const float *__restrict__ row, int64
     }
 }
 
+__device__ __forceinline__ void scan_row_ex(float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
+                                            int max_size, const int *ex, int nex, float &bv, int &bi, const wrefine *rf = nullptr,
+                                            float *sv = nullptr, int *si = nullptr)
+{
+    if (rf) scan_row_refine(row, len, asz, my_size, max_size, ex, nex, bv, bi, rf, sv, si);
+    else scan_row_plain(row, len, asz, my_size, max_size, ex, nex, bv, bi);
+}
+
 // Pops the WB_WTOP smallest keys of a wave (every lane offers k1 < k2, its two smallest; a key with bit 0 set is a SENTINEL:
 // a lower bound of entries that are not listed) into out[0..WB_WTOP), then out[WB_WTOP] = a sentinel for whatever the wave
 // did not report.  A reader that walks such streams in ascending order and stops at the first sentinel has seen every key
@@ -1071,8 +1243,8 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
 // entries wg, wg + WB_R, ... (WB_RM of them), re-minimises each without the batch's members and publishes the result.
 // The finish kernel installs them if the whole batch commits; the preselection waits for the ones it needs.
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
-                                 const int32_t *__restrict__ rownn, const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
-                                 int max_size, ward_state *__restrict__ st, float *sv, int *si)
+                                 const int32_t *__restrict__ rownn, float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
+                                 int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine *rf0 = nullptr)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ int lcnt;
@@ -1176,7 +1348,12 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         float rv = ICL_MAXF;
         int ri = -1;
         if (r >= 0) {
-            scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri);
+            wrefine rf;
+            if (rf0) {
+                rf = *rf0;
+                rf.self_id = r;
+            }
+            scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri, rf0 ? &rf : nullptr, sv, si);
             block_argmin(rv, ri, sv, si);
         }
         if (threadIdx.x == 0) {
@@ -1192,8 +1369,8 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
 }
 
 __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
-                                     const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int max_size,
-                                     ward_state *__restrict__ st, float *sv, int *si, int *sh)
+                                     float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int max_size,
+                                     ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine *rf0 = nullptr)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
@@ -1202,7 +1379,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, target = st->target;
     const int t_after = t0 + nb;
-    if (t_after >= target) { // nothing left to select for
+    if (t_after >= target || nb <= 0) { // nothing left to select for (nb == 0: the spare workgroups publish no streams; the finish kernel selects by itself)
         if (threadIdx.x == 0) {
             st->B.pre_n = 0;
             st->B.ov_n = 0;
@@ -1386,7 +1563,12 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri);
+        wrefine rf;
+        if (rf0) {
+            rf = *rf0;
+            rf.self_id = r;
+        }
+        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, rf0 ? &rf : nullptr, sv, si);
         block_argmin(rv, ri, sv, si); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
@@ -1729,6 +1911,9 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 //     lgkmcnt(0) and the s_load latency is exposed four times per stage: 57 us per block instead of 36.)
 // Arithmetic, row order, masks, keys and the dirty-column protocol are those of ward_update_batch_kernel.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef WX_PRUNE
+#define WX_PRUNE 0                     /* 1: build the partial-sum pruning experiment (ICL_WARD_PRUNE=<beta> then enables it at run time); 0: compiled out -- its refinement code costs the update kernel ~180 spilled VGPRs in the preselection role */
+#endif
 #ifndef WX_R
 #define WX_R 4                         /* ring stages (20 KB each: 16 KB of columns + 4 KB of centroids); depth 4..7 measured within 2 % of each other */
 #endif
@@ -1765,17 +1950,19 @@ __global__ void ward_interleave_kernel(const float *__restrict__ cnewK, int64_t 
 __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       const float *__restrict__ cnewI, int64_t cn_stride,
-                                                                      const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                                      const int32_t *__restrict__ slot_id, const int32_t *__restrict__ id_slot,
+                                                                      const int32_t *__restrict__ asz,
                                                                       const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, int diag)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, int diag, float prune_beta)
 {
     extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
+        const wrefine rf0{Crow, id_slot, d, -1, &st->B.refined};
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, (WX_PRUNE && prune_beta > 0.0f) ? &rf0 : nullptr);
         return;
     }
     if (blockIdx.x == WB_R) {
@@ -1784,7 +1971,8 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         int *sh = si + 16;
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        const wrefine rf0{Crow, id_slot, d, -1, &st->B.refined};
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh, (WX_PRUNE && prune_beta > 0.0f) ? &rf0 : nullptr);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -1970,6 +2158,35 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             else quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, 1>());
         }
     };
+    // ---- partial-sum pruning: tau = beta x (largest pick value of the batch).  A chain wave stops once EVERY lane's partial value
+    // (size factor x in-order partial sum: a lower bound of the final value, sums of non-negative terms only grow) exceeds tau
+    // for both of its chains; its entries are then stored negated ("true value >= this").  tau >= every pick value of the
+    // batch, so a pruned entry can neither precede a pick (the finish kernel's validation) nor be a row minimum that matters
+    // before it is refined (scan_row_ex).  The virtual-slot workgroup never prunes.
+    __shared__ int wexit_stage[WX_CW];
+    const bool prune = WX_PRUNE && prune_beta >= 1.0f && !virt && WX_NS == 1;
+    float tau = ICL_MAXF;
+    float facA = 0.0f, facB = 0.0f; // this lane's size factors for the wave's chains (0: not a valid pair -> never blocks a stop)
+    if (prune) {
+        float vlast = 0.0f;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j)
+            if (j < nb) vlast = fmaxf(vlast, st->B.val[j]);
+        tau = prune_beta * vlast;
+        if (chain) {
+            int sa_ = psc[0], sb_ = psc[0];
+#pragma unroll
+            for (int q = 1; q < WB_K; ++q) {
+                if (q == jA) sa_ = psc[q];
+                if (q == jB) sb_ = psc[q];
+            }
+            if ((okmask[0] >> jA) & 1u) facA = (float)((int64_t)sx[0] * sa_) / (float)(sx[0] + sa_);
+            if (WX_CPW == 2 && jB < nb && ((okmask[0] >> jB) & 1u)) facB = (float)((int64_t)sx[0] * sb_) / (float)(sx[0] + sb_);
+        }
+    }
+    if (threadIdx.x < WX_CW) wexit_stage[threadIdx.x] = (prune && threadIdx.x * WX_CPW < nb) ? (1 << 30) : ((prune ? -1 : (1 << 30))); // idle chain waves count as stopped
+    bool wstopped = false;
+    __syncthreads();
     for (int i = 0; i < nstage; ++i) {
         if (loader) {
             // stage i has landed once at most the WX_R-2 younger stages are outstanding (in the tail nothing new is issued:
@@ -1984,6 +2201,12 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of stage i-1 have returned before its ring slot is refilled
         }
         __builtin_amdgcn_s_barrier();
+        if (prune && i > 0) { // every chain wave stopped during stage <= i-1: nothing left to compute, stop loading too
+            int stopped = 0;
+#pragma unroll
+            for (int q = 0; q < WX_CW; ++q) stopped += wexit_stage[q] <= i - 1;
+            if (stopped == WX_CW && !any_dirty) break; // (dirty columns must still be re-made from every stage)
+        }
         if (loader) {
             if (any_dirty && i >= 2) { // re-make the dirty columns from the stage that has just landed (rare)
 #pragma unroll
@@ -1997,11 +2220,24 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
                 }
             }
             if (i + WX_R - 1 < nstage && do_load) issue(i + WX_R - 1); // into the slot stage i-1 was read from: every chain wave is past this barrier
-        } else if (chain && do_chain) {
+        } else if (chain && do_chain && !wstopped) {
             consume(i);
+            if (prune) {
+                const float pa_ = WX_CPW == 2 ? sP[0].x : sA[0], pb_ = WX_CPW == 2 ? sP[0].y : 0.0f;
+                const bool okA = facA == 0.0f || facA * pa_ > tau, okB = facB == 0.0f || facB * pb_ > tau;
+                if (i + 1 < nstage && __all(okA && okB)) {
+                    wstopped = true;
+                    if (lane == 0) wexit_stage[wave] = i;
+                }
+            }
         }
     }
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the LDS is released
     if (!chain) return;
+    if (prune && lane == 0) {
+        atomicAdd(&st->B.chain_waves, 1ull);
+        if (wstopped) atomicAdd(&st->B.pruned_waves, 1ull);
+    }
 #pragma unroll
     for (int cc = 0; cc < WX_CPW; ++cc) {
         const int j = jA + cc;
@@ -2012,6 +2248,10 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             if (j == q) sc = psc[q];
         const int64_t c = n + t + j;
         const int64_t ro = rowoff[c];
+        int mark = pa[0]; // a_j: dead once c_j exists
+#pragma unroll
+        for (int q = 1; q < WB_K; ++q)
+            if (j == q) mark = pa[q];
         unsigned long long key = ~0ull, key2 = ~0ull;
 #pragma unroll
         for (int u = 0; u < WX_NS; ++u) {
@@ -2020,9 +2260,14 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
                 const float num = (float)((int64_t)sx[u] * (int64_t)sc);
                 const float den = (float)(sx[u] + sc);
                 const float val = (num / den) * s;
-                Dtri[ro + x[u]] = val;
+                // a stopped wave holds partial sums: val is a lower bound (> tau), stored negated.  Its key is the next float
+                // BELOW the bound with the (dead) member a_j as the column: a row whose smallest key is such a bound is installed
+                // dirty (partner dead) and refined when it reaches the top; "strictly below" makes an exact value that equals a
+                // bound lose to it, so ties are always resolved on exact values.
+                Dtri[ro + x[u]] = wstopped ? -val : val;
                 if (val < ICL_MAXF) {
-                    const unsigned long long k = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x[u];
+                    const unsigned long long k = wstopped ? (((unsigned long long)(__float_as_uint(val) - 1u) << 32) | (unsigned long long)(unsigned)mark)
+                                                          : (((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x[u]);
                     key = k < key ? k : key;
                     // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the
                     // validation needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's
@@ -2192,7 +2437,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                                                                 float *__restrict__ cnewK, int64_t cn_stride, int32_t *__restrict__ slot_id,
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
                                                                 float *__restrict__ rowmin, int32_t *__restrict__ rownn,
-                                                                int32_t *__restrict__ merges, const float *__restrict__ Dtri,
+                                                                int32_t *__restrict__ merges, float *__restrict__ Dtri,
                                                                 const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st, int lw)
 {
     // lw != 0 (FAST mode): the rows come from the Lance-Williams recurrence, no centroid is kept: only the bookkeeping runs
@@ -2627,8 +2872,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 const unsigned long long key = ls.B.ckey[j];
                 if (key != ~0ull) {
                     const int x = (int)(key & 0xffffffffu);
-                    bool died = false; // its minimum partner may have been merged later in the same batch
-                    for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]);
+                    bool died = x == ls.B.a[j]; // a pruned row's key carries its own (dead) member a_j: a bound only, to be refined
+                    for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]); // or its minimum partner was merged later in the same batch
                     crow[j] = (int)(n + t0 + j);
                     cnn[j] = died ? -2 : x;
                     cval[j] = __uint_as_float((unsigned)(key >> 32));
@@ -2792,7 +3037,12 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             if (!dirty) break;
             float rv;
             int ri;
-            scan_row(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, rv, ri);
+            {
+                // rows written by the pruning update kernel may hold flagged lower bounds: refine on demand (no exclusions here)
+                const wrefine rf{Crow, id_slot, d, bi, &st->B.refined};
+                const int noex[1] = {-1};
+                scan_row_ex(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, noex, 0, rv, ri, (WX_PRUNE && !lw) ? &rf : nullptr, sv, si);
+            }
             block_argmin(rv, ri, sv, si);
             if (threadIdx.x == 0) {
                 rowmin[bi] = rv;
@@ -3294,19 +3544,28 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const int dqb = (int)wb_groups(d);
         const unsigned lw_blocks_b = (unsigned)icl_ceil_div(w->S, WB_THREADS) + 2 + WB_R;
         const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * dqb * 16;
-        if (!lw && wb_lds_bytes > 158 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
-        static bool wb_attr = false;
-        if (!wb_attr) {
-            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); // + the preselection's static arrays
-            wb_attr = true;
-        }
         const unsigned wb_blocks = (unsigned)((w->S / 64 + 7) / 8 * 8) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
         // ICL_WARD_UPD=1 selects the first-generation kernel (WB_NH workgroups per slot block) for A/B measurements
         static const bool gen2 = [] {
             const char *e = getenv("ICL_WARD_UPD");
             return !(e && e[0] == '1');
         }();
+        if (!lw && !gen2) { // first-generation kernel only: its LDS holds whole centroid images
+            if (wb_lds_bytes > 150 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the first-generation update kernel's LDS image", d);
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb_lds_bytes));
+        }
         const size_t wx_lds_bytes = (size_t)WX_R * WX_STAGE_F4 * 16;
+        // ICL_WARD_PRUNE=<beta>: partial-sum pruning (tau = beta x the batch's largest pick value).  OFF by default: exact and
+        // parity-green (every large-N test passes with it), and it cuts the update workgroup from 45 to 31 us (98 % of the chain
+        // waves stop within 3 of 32 stages), but rows that become ISOLATED -- their near partners are gone, the next candidate
+        // is 100x farther -- must later be made exact entry by entry on one workgroup (1.2e8 refined entries at N = 100 000:
+        // merge loop 1.5 s -> 20 s on the mixture-of-Gaussians input, 3.1 s on the ResNet embeddings).  It pays only once such
+        // rows are re-bounded in batches by the update kernel itself.
+        static const float wx_prune = [] {
+            const char *e = getenv("ICL_WARD_PRUNE");
+            const float b = e ? (float)atof(e) : 0.0f;
+            return (WX_PRUNE && b >= 1.0f) ? b : 0.0f;
+        }();
         static const int wx_diag = [] { // ICL_WX_DIAG: 1 = no chain arithmetic, 2 = no column loads (kernel timing experiments; WRONG results)
             const char *e = getenv("ICL_WX_DIAG");
             return e ? atoi(e) : 0;
@@ -3314,7 +3573,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const unsigned wx_blocks = (unsigned)((w->S / 64 + WX_NS - 1) / WX_NS) + 2 + WB_R;
         static bool wx_attr = false;
         if (!wx_attr) {
-            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             wx_attr = true;
         }
         auto finish_b = [&]() {
@@ -3332,7 +3591,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
             if (gen2)
                 hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
-                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag);
+                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag, wx_prune);
             else
                 hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                    w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
@@ -3374,7 +3633,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         auto finished = [&](const ward_state &h) { return h.done || h.t >= T; };
         int rc_b = ICL_OK;
         int64_t chunk = 0;
-        const int64_t max_chunks = T / GRAPH_STEPS + 3; // every step commits at least one merge until the end
+        const int64_t max_chunks = 2 * (T / GRAPH_STEPS) + 8; // every step commits at least one merge until the end (slack: a safety bound, not a schedule)
         bool fin = T == 0;
         while (!fin && chunk < max_chunks) {
             if (use_graph) {
@@ -3430,6 +3689,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
                 hst.B.slow, hst.B.general);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] pruning: %llu of %llu chain waves stopped early; %llu entries refined on demand\n", hst.B.pruned_waves, hst.B.chain_waves, hst.B.refined);
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
 #ifdef ICL_WARD_TIMERS

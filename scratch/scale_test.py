@@ -13,16 +13,26 @@ if __name__ == "__main__":
     ap.add_argument("--lw", action="store_true")
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--d", type=int, default=2048)
+    ap.add_argument("--real", action="store_true", help="cluster the bf16 ResNet50 embeddings of the bench's structured synthetic images instead of the mixture of Gaussians")
     a = ap.parse_args()
     if a.lib:
         _lib.SO_PATH = a.lib
     n, d = a.n, a.d
     ctx = _lib.Context(0)
-    g = torch.Generator(device="cuda"); g.manual_seed(1)
-    k = n // 20
-    cen = torch.randn((k, d), generator=g, device="cuda")
-    lab = torch.randint(0, k, (n,), generator=g, device="cuda")
-    E = (cen[lab] + 0.1 * torch.randn((n, d), generator=g, device="cuda")).contiguous()
+    if a.real:
+        ctx.load_synthetic(1)
+        imgs = torch.empty(n * _lib.IMG_BYTES, dtype=torch.uint8, device="cuda")
+        ctx.synth_images_dev(20250217, 0, n, _lib.SYNTH_STRUCTURED, imgs.data_ptr())
+        E = torch.empty((n, 2048), dtype=torch.float32, device="cuda")
+        ctx.embed_u8_dev(imgs.data_ptr(), n, E.data_ptr(), 2048, _lib.PREC_BF16)
+        del imgs
+        d = 2048
+    else:
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        k = n // 20
+        cen = torch.randn((k, d), generator=g, device="cuda")
+        lab = torch.randint(0, k, (n,), generator=g, device="cuda")
+        E = (cen[lab] + 0.1 * torch.randn((n, d), generator=g, device="cuda")).contiguous()
     torch.cuda.synchronize()
     modes = [(_lib.UPDATE_EXACT, "exact")] + ([(_lib.UPDATE_LW, "lw")] if a.lw else [])
     for upd, name in modes:
