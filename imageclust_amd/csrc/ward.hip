@@ -61,6 +61,7 @@ struct ward_batch_state {
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
+    int32_t blk_next, blk_pad;       // the persistent main workgroups' block counter (zeroed every step by ward_interleave_kernel)
     unsigned long long refined, pruned_waves, chain_waves, dirty_rows; // pruning statistics: entries made exact on demand; chain waves that stopped early / ran; new rows installed with a bound only
     unsigned long long prune_hist[4][34]; // -DICL_WARD_TIMERS what-if: [beta index][stage a chain wave could stop at (32 = never), 33 = rows whose minimum exceeds tau]
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
@@ -474,6 +475,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         for (int j = 0; j < 4 * 34; ++j) (&st->B.prune_hist[0][0])[j] = 0;
         st->B.refined = st->B.pruned_waves = st->B.chain_waves = st->B.dirty_rows = 0;
+        st->B.blk_next = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
     }
 }
@@ -1915,7 +1917,7 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 #define WX_PRUNE 0                     /* 1: build the partial-sum pruning experiment (ICL_WARD_PRUNE=<beta> then enables it at run time); 0: compiled out -- its refinement code costs the update kernel ~180 spilled VGPRs in the preselection role */
 #endif
 #ifndef WX_R
-#define WX_R 4                         /* ring stages (20 KB each: 16 KB of columns + 4 KB of centroids); depth 4..7 measured within 2 % of each other */
+#define WX_R 3                         /* ring stages (40 KB each with 32 k-groups per stage: 32 KB of columns + 8 KB of centroids); depth 4..7 at 16 groups per stage measured within 2 % of each other */
 #endif
 #ifndef WX_L
 #define WX_L 4                         /* loader waves (4 or 2) */
@@ -1923,31 +1925,39 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 #define WX_CW 8                        /* chain waves */
 #define WX_CPW ((WB_K + WX_CW - 1) / WX_CW) /* chains per chain wave */
 #define WX_THREADS (64 * (WX_L + WX_CW))
-#define WX_XOPS (WB_SG / WX_L)         /* column pieces per loader wave and stage */
-#define WX_COPS (4 / WX_L)             /* centroid pieces per loader wave and stage (4 pieces: chains 4p .. 4p+3, 16 k-groups each) */
+#ifndef WX_SG
+#define WX_SG 32                       /* k-groups per ring stage (one raw barrier per stage: 32 halves the barriers of a block against 16) */
+#endif
+#define WX_XOPS (WX_SG / WX_L)         /* column pieces per loader wave and stage */
+#define WX_CPIECES (WX_NCH * WX_SG / 64) /* centroid pieces per stage: 16 chains x WX_SG k-groups x 16 B in 1 KB pieces */
+#define WX_COPS (WX_CPIECES / WX_L)    /* ... per loader wave */
 #define WX_OPS (WX_XOPS + WX_COPS)
 #define WX_NCH 16                      /* chains the centroid pieces always cover (cnew is allocated for 16) */
 #ifndef WX_NS
 #define WX_NS 1                        /* sets of 64 slots per workgroup (they share the centroid reads and the per-workgroup overhead).  Measured: 2 sets = 89 us per 128 slots against 47.7 us per 64 -- the chain waves are VALU-issue bound (8 instructions per chain and k-group at 4 cycles each: 27 us floor per 64 slots and 16 chains), so sharing LDS reads buys 6 % at N=100k and costs 30 % at N=10k (half as many workgroups) */
 #endif
-#define WX_STAGE_F4 (WX_NS * WB_SG * 64 + WX_NCH * WB_SG) /* float4 per ring stage: WX_NS sets of columns, then [chain][k-group] centroids */
-static_assert(WB_SG == 16 && WB_SG % WX_L == 0, "a stage is 16 k-groups, dealt evenly to the loader waves");
+#define WX_STAGE_F4 (WX_NS * WX_SG * 64 + WX_NCH * WX_SG) /* float4 per ring stage: WX_NS sets of columns, then [chain][k-group] centroids */
+static_assert(WX_SG % 16 == 0 && WX_SG % WX_L == 0 && WX_CPIECES % WX_L == 0 && WX_SG % WB_SG == 0, "a stage is dealt evenly to the loader waves");
 static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
 
 // The new centroids of chains 2p and 2p+1, interleaved element by element: cnewI[p][k] = {c_2p[k], c_2p+1[k]}.  A chain wave
 // runs both chains of its pair with PACKED fp32 ops ({x[k], x[k]} - {cA[k], cB[k]}, squared, added to {sA, sB}: 3 v_pk
 // instructions per k for two chains instead of 4 -- the update kernel is VALU-issue bound), which needs cA[k] and cB[k] in
 // one register pair.  Runs after every finish kernel (which writes cnewK), 128 KB.
-__global__ void ward_interleave_kernel(const float *__restrict__ cnewK, int64_t cn_stride, float *__restrict__ cnewI)
+__global__ void ward_interleave_kernel(const float *__restrict__ cnewK, int64_t cn_stride, float *__restrict__ cnewI, ward_state *__restrict__ st)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (pair, k)
+    if (i == 0) st->B.blk_next = 0; // the next update launch's persistent workgroups draw their blocks from 0
     const int64_t p = i / cn_stride, k = i % cn_stride;
     if (p >= WB_K / 2) return;
     const float2 v = make_float2(cnewK[(2 * p) * cn_stride + k], cnewK[(2 * p + 1) * cn_stride + k]);
     reinterpret_cast<float2 *>(cnewI)[p * cn_stride + k] = v;
 }
 
-__global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+#ifndef WX_WGS_PER_CU
+#define WX_WGS_PER_CU 1                /* main workgroups resident per CU (2 needs <= 80 VGPRs and <= 76 KB of LDS each: WX_SG=16, WX_R=3) */
+#endif
+__global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       const float *__restrict__ cnewI, int64_t cn_stride,
                                                                       const int32_t *__restrict__ slot_id, const int32_t *__restrict__ id_slot,
@@ -1980,12 +1990,8 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WB_TIMER(const unsigned long long tm0 = wall_clock64();)
     const bool virt = blockIdx.x == WB_R + 1; // "virtual slots": lane i = tentative cluster c_i, column = its new centroid
-    const int64_t mblk = virt ? 0 : (int64_t)blockIdx.x - (WB_R + 2);
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     if (done || nb <= 0) return;
-    // A workgroup owns WX_NS sets of 64 consecutive slots (the virtual-slot workgroup: one set).  The sets share every
-    // centroid read and the per-launch overhead; a set beyond the live range is simply inactive.
-    if (!virt && mblk * (64 * WX_NS) >= nlive) return;
     const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
     int pa[WB_K], pb[WB_K], psc[WB_K];
 #pragma unroll
@@ -1994,17 +2000,84 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         pb[j] = st->B.b[j];
         psc[j] = st->B.sa[j] + st->B.sb[j];
     }
+    // PERSISTENT main workgroups: the grid holds at most one per CU; each draws 64-slot blocks from a device-wide counter
+    // (reset every step by ward_interleave_kernel) until the live range is exhausted.  The per-launch state above is read
+    // once per workgroup instead of once per block, there is no workgroup launch per block, and workgroups that start late
+    // (their CU ran a spare / preselection workgroup first) simply draw fewer blocks.
+    __shared__ int cur_blk;
+    __shared__ int wexit_stage[WX_CW];
+    for (bool first = true;; first = false) {
+    __syncthreads(); // the previous block's ring reads and its cur_blk reads are done
+    if (threadIdx.x == 0) cur_blk = virt ? (first ? 0 : -1) : atomicAdd(&st->B.blk_next, 1);
+    __syncthreads();
+    const int64_t mblk = cur_blk;
+    // A workgroup owns WX_NS sets of 64 consecutive slots (the virtual-slot workgroup: one set).  The sets share every
+    // centroid read and the per-launch overhead; a set beyond the live range is simply inactive.
+    if (mblk < 0 || (!virt && mblk * (64 * WX_NS) >= nlive)) break;
     int64_t slot[WX_NS];
     int x[WX_NS], sx[WX_NS];
     unsigned okmask[WX_NS];
     bool survives[WX_NS], dirty_lane[WX_NS], set_on[WX_NS];
     const int dq_real = d >> 2;
     bool any_ok = false, any_dirty = false;
+    // ---- part 1: what the loaders need (slot, live sets, dirty columns) -- then the ring's first stages are requested BEFORE
+    // the dependent slot_id -> asz loads of part 2, which resolve while the DMA is in flight
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) {
         slot[u] = virt ? lane : (mblk * WX_NS + u) * 64 + lane;
         set_on[u] = virt ? u == 0 : (mblk * WX_NS + u) * 64 < nlive; // wave-uniform
-        // which rows does this lane's cluster take part in?
+        // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
+        // streams its centroid from the row-major copy instead and the column is re-made on the way
+        dirty_lane[u] = false;
+        const int nd = (virt || !set_on[u]) ? 0 : dirty_n0;
+        for (int z = 0; z < nd; ++z) dirty_lane[u] |= __shfl(dirty_s0, z, 64) == (int)slot[u];
+        any_dirty |= __any(dirty_lane[u]);
+    }
+    const int nstage = (dqp + WX_SG - 1) / WX_SG; // the CT4 columns and the centroid images are zero-padded past dqp: (0-0)^2 adds +0
+    const bool loader = wave >= WX_CW;
+    const int pj = wave - WX_CW; // loader index
+    const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
+    const int64_t row_bytes = virt ? 16 : S * 16;
+    const unsigned ring_base = lds_addr_of(wb_lds);
+    // centroid pieces.  WX_CPW == 2: the ring holds [pair][k-group][2] float4 = {cA[4g+2h], cB[4g+2h], cA[4g+2h+1], cB[4g+2h+1]} from the
+    // interleaved copy: lane l of piece q fetches pair 2q + l/32, k-group (l%32)/2, half l%2.  WX_CPW == 1: [chain][k-group] from cnewK.
+    // piece q of a stage covers ring float4 indices [64q, 64q+64) of the centroid area; index = unit * WX_SG*(WX_CPW==2 ? 2 : 1) + within,
+    // unit = pair (WX_CPW == 2: within = 2*g + h) or chain (within = g)
+    auto csrc_of = [&](int q, int stage) -> const char * {
+        const int idx = q * 64 + lane;
+        if (WX_CPW == 2) {
+            const int pair = idx / (2 * WX_SG), w = idx % (2 * WX_SG), g = w >> 1, h = w & 1;
+            return reinterpret_cast<const char *>(cnewI) + ((int64_t)pair * 2 * cn_stride + ((int64_t)stage * WX_SG + g) * 8 + h * 4) * 4;
+        }
+        const int ch = idx / WX_SG, g = idx % WX_SG;
+        return reinterpret_cast<const char *>(cnewK) + ((int64_t)ch * cn_stride + ((int64_t)stage * WX_SG + g) * 4) * 4;
+    };
+    auto issue = [&](int stage) { // this loader wave's pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
+        const int g0 = stage * WX_SG + pj * WX_XOPS;
+        const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
+#pragma unroll
+        for (int u = 0; u < WX_NS; ++u) {
+            if (!set_on[u]) continue; // an inactive set's ring area is never read
+            const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot[u] * 16;
+#pragma unroll
+            for (int q = 0; q < WX_XOPS; ++q) {
+                const int g = g0 + q;
+                const char *src = ctb + (int64_t)g * row_bytes + voff;
+                if (dirty_lane[u] && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot[u] * d + (int64_t)g * 4) * 4;
+                glds16_asm(src, sbase + (unsigned)((u * WX_SG + pj * WX_XOPS + q) * 1024));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WX_COPS; ++q)
+            glds16_asm(csrc_of(pj * WX_COPS + q, stage), sbase + (unsigned)(WX_NS * WX_SG * 1024 + (pj * WX_COPS + q) * 1024));
+    };
+    const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
+    const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
+    if (loader && do_load)
+        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i);
+    // ---- part 2: which rows does this lane's cluster take part in?
+#pragma unroll
+    for (int u = 0; u < WX_NS; ++u) {
         if (virt) {
             x[u] = (u == 0 && lane < nb) ? (int)(n + t + lane) : -1;
             sx[u] = 0;
@@ -2030,16 +2103,12 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             }
         }
         survives[u] = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
-        // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
-        // streams its centroid from the row-major copy instead and the column is re-made on the way
-        dirty_lane[u] = false;
-        const int nd = (virt || !set_on[u]) ? 0 : dirty_n0;
-        for (int z = 0; z < nd; ++z) dirty_lane[u] |= __shfl(dirty_s0, z, 64) == (int)slot[u];
         any_ok |= __any(okmask[u] != 0);
-        any_dirty |= __any(dirty_lane[u]);
     }
     if (!any_ok) {
-        // nothing to compute here, but a stale column must not outlive this step's dirty list
+        // nothing to compute here (the requested stages must land before the ring is reused), but a stale column must not
+        // outlive this step's dirty list
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < WX_NS; ++u) {
             unsigned long long dm = __ballot(dirty_lane[u]);
@@ -2051,43 +2120,8 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
                     *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
             }
         }
-        return;
+        continue;
     }
-    const int nstage = dqp / WB_SG;
-    const bool loader = wave >= WX_CW;
-    const int pj = wave - WX_CW; // loader index
-    const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
-    const int64_t row_bytes = virt ? 16 : S * 16;
-    const unsigned ring_base = lds_addr_of(wb_lds);
-    // centroid pieces.  WX_CPW == 2: the ring holds [pair][k-group][2] float4 = {cA[4g+2h], cB[4g+2h], cA[4g+2h+1], cB[4g+2h+1]} from the
-    // interleaved copy: lane l of piece q fetches pair 2q + l/32, k-group (l%32)/2, half l%2.  WX_CPW == 1: [chain][k-group] from cnewK.
-    const int64_t pc0 = WX_COPS * (pj & (WX_L - 1));
-    const char *csrc = WX_CPW == 2 ? reinterpret_cast<const char *>(cnewI) + ((int64_t)(2 * pc0 + (lane >> 5)) * 2 * cn_stride + (int64_t)((lane & 31) >> 1) * 8 + (lane & 1) * 4) * 4
-                                   : reinterpret_cast<const char *>(cnewK) + ((int64_t)(4 * pc0 + (lane >> 4)) * cn_stride + (int64_t)(lane & 15) * 4) * 4;
-    auto issue = [&](int stage) { // this loader wave's pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
-        const int g0 = stage * WB_SG + pj * WX_XOPS;
-        const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
-#pragma unroll
-        for (int u = 0; u < WX_NS; ++u) {
-            if (!set_on[u]) continue; // an inactive set's ring area is never read
-            const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot[u] * 16;
-#pragma unroll
-            for (int q = 0; q < WX_XOPS; ++q) {
-                const int g = g0 + q;
-                const char *src = ctb + (int64_t)g * row_bytes + voff;
-                if (dirty_lane[u] && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot[u] * d + (int64_t)g * 4) * 4;
-                glds16_asm(src, sbase + (unsigned)((u * WB_SG + pj * WX_XOPS + q) * 1024));
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < WX_COPS; ++q)
-            glds16_asm(csrc + (int64_t)q * 4 * cn_stride * 4 + (int64_t)stage * (WB_SG * (WX_CPW == 2 ? 32 : 16)),
-                       sbase + (unsigned)(WX_NS * WB_SG * 1024 + (pj * WX_COPS + q) * 1024));
-    };
-    const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
-    const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
-    if (loader && do_load)
-        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i);
     const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * WX_CPW : 0);
     const int jB = __builtin_amdgcn_readfirstlane(jA + (WX_CPW - 1));
     const bool chain = wave < WX_CW && jA < nb;
@@ -2099,13 +2133,16 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) sP[u] = f2{0.0f, 0.0f};
     // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
+    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times.
+    // (Measured and dropped: an explicit two-register-set software pipeline across quarters -- reads of quarter q+1 issued before
+    // quarter q is computed -- is SLOWER than hipcc's own interleaving of the same reads: 54 vs 45 us per block.)
     auto quarter = [&](const float4 *xr, const float4 *ca, const float4 *cb, auto nsets_tag) {
         constexpr int NSETS = decltype(nsets_tag)::value;
         float4 xv[NSETS][4], c0[4], c1[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int u = 0; u < NSETS; ++u) xv[u][g] = xr[(u * WB_SG + g) * 64];
+            for (int u = 0; u < NSETS; ++u) xv[u][g] = xr[(u * WX_SG + g) * 64];
             if (WX_CPW == 2) {
                 c0[g] = ca[2 * g];     // {cA[4g], cB[4g], cA[4g+1], cB[4g+1]}
                 c1[g] = ca[2 * g + 1]; // {cA[4g+2], cB[4g+2], cA[4g+3], cB[4g+3]}
@@ -2149,10 +2186,10 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         const float4 *sb_ = wb_lds + (stage % WX_R) * WX_STAGE_F4;
         const float4 *xr = sb_ + lane;
         // wave-uniform addresses: broadcast reads.  WX_CPW == 2: this wave's pair, [k-group][2 halves]; else [chain][k-group]
-        const float4 *ca = sb_ + WX_NS * WB_SG * 64 + (WX_CPW == 2 ? (jA >> 1) * (2 * WB_SG) : jA * WB_SG);
+        const float4 *ca = sb_ + WX_NS * WX_SG * 64 + (WX_CPW == 2 ? (jA >> 1) * (2 * WX_SG) : jA * WX_SG);
         const float4 *cb = ca;
 #pragma unroll
-        for (int q = 0; q < WB_SG / 4; ++q) {
+        for (int q = 0; q < WX_SG / 4; ++q) {
             const float4 *cq = ca + q * 4 * (WX_CPW == 2 ? 2 : 1);
             if (two) quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, WX_NS>());
             else quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, 1>());
@@ -2163,7 +2200,6 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
     // for both of its chains; its entries are then stored negated ("true value >= this").  tau >= every pick value of the
     // batch, so a pruned entry can neither precede a pick (the finish kernel's validation) nor be a row minimum that matters
     // before it is refined (scan_row_ex).  The virtual-slot workgroup never prunes.
-    __shared__ int wexit_stage[WX_CW];
     const bool prune = WX_PRUNE && prune_beta >= 1.0f && !virt && WX_NS == 1;
     float tau = ICL_MAXF;
     float facA = 0.0f, facB = 0.0f; // this lane's size factors for the wave's chains (0: not a valid pair -> never blocks a stop)
@@ -2208,13 +2244,13 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             if (stopped == WX_CW && !any_dirty) break; // (dirty columns must still be re-made from every stage)
         }
         if (loader) {
-            if (any_dirty && i >= 2) { // re-make the dirty columns from the stage that has just landed (rare)
+            if (any_dirty && i * WX_SG >= 2 * WB_SG) { // re-make the dirty columns (beyond the groups the finish kernel re-made) from the stage that has just landed (rare)
 #pragma unroll
                 for (int u = 0; u < WX_NS; ++u) {
-                    const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + u * WB_SG * 64 + lane;
+                    const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + u * WX_SG * 64 + lane;
 #pragma unroll
                     for (int q = 0; q < WX_XOPS; ++q) {
-                        const int g = i * WB_SG + pj * WX_XOPS + q;
+                        const int g = i * WX_SG + pj * WX_XOPS + q;
                         if (dirty_lane[u] && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot[u])) = xr[(pj * WX_XOPS + q) * 64];
                     }
                 }
@@ -2232,8 +2268,8 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
             }
         }
     }
-    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the LDS is released
-    if (!chain) return;
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the ring is reused / the LDS released
+    if (!chain) continue;
     if (prune && lane == 0) {
         atomicAdd(&st->B.chain_waves, 1ull);
         if (wstopped) atomicAdd(&st->B.pruned_waves, 1ull);
@@ -2288,6 +2324,7 @@ __global__ __launch_bounds__(WX_THREADS) void ward_update_batch2_kernel(int d, i
         WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
+    } // block loop
 }
 
 // FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
@@ -3570,7 +3607,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             const char *e = getenv("ICL_WX_DIAG");
             return e ? atoi(e) : 0;
         }();
-        const unsigned wx_blocks = (unsigned)((w->S / 64 + WX_NS - 1) / WX_NS) + 2 + WB_R;
+        // main workgroups: persistent, at most one per CU (they draw blocks from a counter); fewer when the input has fewer blocks
+        const unsigned wx_blocks = (unsigned)std::min<int64_t>((w->S / 64 + WX_NS - 1) / WX_NS, (int64_t)WX_WGS_PER_CU * ctx->prop.multiProcessorCount) + 2 + WB_R;
         static bool wx_attr = false;
         if (!wx_attr) {
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
@@ -3579,9 +3617,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0);
-            if (!lw && gen2 && WX_CPW == 2) // the pair-interleaved copy of the centroids the finish kernel has just written
+            if (!lw && gen2) // the pair-interleaved copy of the centroids the finish kernel has just written + the block counter reset
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
-                                   w->cn_stride, w->cnewI);
+                                   w->cn_stride, w->cnewI, w->st);
         };
         auto update_b = [&]() {
             if (lw) {

@@ -1,8 +1,8 @@
 """Scale check of the exact Ward engine on one GPU (not a pytest: takes tens of seconds and tens of GB).
 usage: python scratch/scale_test.py N [--lib path/to/variant.so] [--lw] [--reps R]"""
-import argparse, sys, time
+import argparse, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imageclust_amd import _lib
 import torch
 
