@@ -1954,6 +1954,130 @@ __global__ void ward_interleave_kernel(const float *__restrict__ cnewK, int64_t 
     reinterpret_cast<float2 *>(cnewI)[p * cn_stride + k] = v;
 }
 
+// The record ward_finish_batch_kernel leaves for ward_finish_data_kernel (int32 words behind cnewI)
+#define WB_FD_SLOT_A 8
+#define WB_FD_FROM (WB_FD_SLOT_A + WB_K)
+#define WB_FD_TO (WB_FD_FROM + WB_K)
+#define WB_FD_SLA (WB_FD_TO + WB_K)
+#define WB_FD_SLB (WB_FD_SLA + WB_K)
+#define WB_FD_SA (WB_FD_SLB + WB_K)
+#define WB_FD_SB (WB_FD_SA + WB_K)
+#define WB_FD_WORDS (WB_FD_SB + WB_K)
+
+// The data phase of an express finish step, one k-group per thread over d/256 workgroups instead of one (the single
+// workgroup spent ~17 us pulling ~1 MB through one CU): centroid images of the committed clusters (cnew_j into a's slot,
+// THEN the compaction move) and the merged centroids of the next batch (clustering.go:37-40), in chunks of 8 commits /
+// picks so that every load of a chunk is in flight at once, plus the pair-interleaved copy of the new centroids.  The
+// express path is only taken when nothing reads a slot written here, so the chunks are independent; every old cnew row is
+// read before any new one is written (same thread, same addresses: program order).  After a non-express step (the finish
+// kernel wrote the centroids itself) only the interleaved copy is re-made.  Either way the update kernel's block counter is reset.
+#define WB_FD_THREADS 64
+__global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow, float *cnewK,
+                                                                         float *__restrict__ cnewI, int64_t cn_stride, const int32_t *__restrict__ fdrec,
+                                                                         ward_state *__restrict__ st)
+{
+    const int64_t i = (int64_t)blockIdx.x * WB_FD_THREADS + threadIdx.x;
+    if (i == 0) st->B.blk_next = 0; // the next update launch's persistent workgroups draw their blocks from 0
+    if (!fdrec[0]) {
+        const int64_t p = i / cn_stride, k = i % cn_stride; // (pair, k)
+        if (p >= WB_K / 2) return;
+        const float2 v = make_float2(cnewK[(2 * p) * cn_stride + k], cnewK[(2 * p + 1) * cn_stride + k]);
+        reinterpret_cast<float2 *>(cnewI)[p * cn_stride + k] = v;
+        return;
+    }
+    if (i >= (d >> 2)) return;
+    const int g = (int)i;
+    const int J = fdrec[1], np = fdrec[2];
+    const unsigned long long deadm = ((unsigned long long)(unsigned)fdrec[4] << 32) | (unsigned)fdrec[3]; // records overwritten later
+    const int32_t *cm_slot_a = fdrec + WB_FD_SLOT_A, *cm_from = fdrec + WB_FD_FROM, *cm_to = fdrec + WB_FD_TO;
+    const int32_t *pk_sla = fdrec + WB_FD_SLA, *pk_slb = fdrec + WB_FD_SLB, *pk_sa = fdrec + WB_FD_SA, *pk_sb = fdrec + WB_FD_SB;
+    // Named values, not arrays: hipcc keeps float4 arrays of this size in scratch memory here, and without the fence it
+    // sinks every load next to its store (load, wait, store, ...), serialising the round trips.
+    auto chunk = [&](const int c0) {
+        const float *dummy = cnewK; // unused entries read a valid row: straight-line code
+        auto ld_w = [&](int r) { // write record r of this chunk: even = cnew_j -> slot_a_j, odd = content of from_j -> to_j
+            const int j = c0 + (r >> 1);
+            const float *src = dummy;
+            if (j < J) {
+                if (r & 1) {
+                    const int fr = cm_from[j];
+                    if (fr >= 0) src = Crow + (int64_t)fr * d;
+                } else
+                    src = cnewK + j * cn_stride;
+            }
+            return reinterpret_cast<const float4 *>(src)[g];
+        };
+        auto st_w = [&](int r, const float4 &v) {
+            const int j = c0 + (r >> 1);
+            if (j >= J) return;
+            const int sr = (r & 1) ? cm_to[j] : cm_slot_a[j];
+            if (sr < 0 || ((deadm >> (2 * c0 + r)) & 1ull)) return;
+            reinterpret_cast<float4 *>(Crow + (int64_t)sr * d)[g] = v;
+            if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sr)) = v;
+        };
+        auto ld_p = [&](int q, bool second) { // centroid of a member of pick c0+q
+            const int j = c0 + q;
+            const float *src = dummy;
+            if (j < np) {
+                const int sel = second ? pk_slb[j] : pk_sla[j]; // >= 0: Crow slot; < 0: old cnew row -1-sel
+                src = sel >= 0 ? Crow + (int64_t)sel * d : cnewK + (int64_t)(-1 - sel) * cn_stride;
+            }
+            return reinterpret_cast<const float4 *>(src)[g];
+        };
+        auto mk_p = [&](int q, const float4 &av, const float4 &bv) { // merged centroid of pick c0+q (unused when there is none)
+            const int j = c0 + q < np ? c0 + q : 0;
+            const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
+            float4 o;
+            { const float pa = fa * av.x; const float pb = fb * bv.x; const float sm = pa + pb; o.x = sm / fs; }
+            { const float pa = fa * av.y; const float pb = fb * bv.y; const float sm = pa + pb; o.y = sm / fs; }
+            { const float pa = fa * av.z; const float pb = fb * bv.z; const float sm = pa + pb; o.z = sm / fs; }
+            { const float pa = fa * av.w; const float pb = fb * bv.w; const float sm = pa + pb; o.w = sm / fs; }
+            return o;
+        };
+        auto st_pp = [&](int q, const float4 &o0, const float4 &o1) { // picks c0+q (even) and c0+q+1: rows of cnewK + their interleaved image
+            const int j = c0 + q;
+            if (j >= np) return;
+            reinterpret_cast<float4 *>(cnewK + j * cn_stride)[g] = o0;
+            float *ci = cnewI + ((int64_t)(j >> 1) * cn_stride + 4 * g) * 2;
+            if (j + 1 < np) {
+                reinterpret_cast<float4 *>(cnewK + (j + 1) * cn_stride)[g] = o1;
+                reinterpret_cast<float4 *>(ci)[0] = make_float4(o0.x, o1.x, o0.y, o1.y);
+                reinterpret_cast<float4 *>(ci)[1] = make_float4(o0.z, o1.z, o0.w, o1.w);
+            } else { // the pair's second chain keeps its old (unused) row
+                ci[0] = o0.x;
+                ci[2] = o0.y;
+                ci[4] = o0.z;
+                ci[6] = o0.w;
+            }
+        };
+#define WB_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define WB_REP16(M) WB_REP8(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define WB_LDW(r) const float4 w##r = ld_w(r);
+#define WB_LDP(q) const float4 a##q = ld_p(q, false), b##q = ld_p(q, true);
+#define WB_STW(r) st_w(r, w##r);
+#define WB_MKP(q) const float4 o##q = mk_p(q, a##q, b##q);
+        WB_REP16(WB_LDW)
+        WB_REP8(WB_LDP)
+        asm volatile("" ::: "memory");
+        WB_REP16(WB_STW)
+        WB_REP8(WB_MKP)
+        st_pp(0, o0, o1);
+        st_pp(2, o2, o3);
+        st_pp(4, o4, o5);
+        st_pp(6, o6, o7);
+#undef WB_LDW
+#undef WB_LDP
+#undef WB_STW
+#undef WB_MKP
+#undef WB_REP8
+#undef WB_REP16
+    };
+    const int cmax = J > np ? J : np;
+    chunk(0);
+    if (WB_K > 8 && 8 < cmax) chunk(8);
+    static_assert(WB_K <= 16, "two chunks of 8 commits / picks");
+}
+
 #ifndef WX_WGS_PER_CU
 #define WX_WGS_PER_CU 1                /* main workgroups resident per CU (2 needs <= 80 VGPRs and <= 76 KB of LDS each: WX_SG=16, WX_R=3) */
 #endif
@@ -2475,8 +2599,12 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
                                                                 float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                                                 int32_t *__restrict__ merges, float *__restrict__ Dtri,
-                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st, int lw)
+                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st, int lw,
+                                                                int32_t *__restrict__ fdrec)
 {
+    // fdrec != nullptr: the express path's data phase runs in ward_finish_data_kernel (several workgroups) from the record
+    // written here; nullptr: it runs below on this one workgroup (ICL_WARD_FD=0, A/B switch)
+    if (fdrec && threadIdx.x == 0) fdrec[0] = 0;
     // lw != 0 (FAST mode): the rows come from the Lance-Williams recurrence, no centroid is kept: only the bookkeeping runs
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -2730,6 +2858,26 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     const bool fast = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // the preselection's assumption held
     WB_TIMER(if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;)
     if (sh[2] && lw) return;
+    if (sh[2] && fdrec) { // the record of this step's data phase (same thread as the reset above writes the valid flag)
+        const int x = threadIdx.x;
+        if (x < WB_K) {
+            fdrec[WB_FD_SLOT_A + x] = cm_slot_a[x];
+            fdrec[WB_FD_FROM + x] = cm_from[x];
+            fdrec[WB_FD_TO + x] = cm_to[x];
+            fdrec[WB_FD_SLA + x] = pk_sla[x];
+            fdrec[WB_FD_SLB + x] = pk_slb[x];
+            fdrec[WB_FD_SA + x] = pk_sa[x];
+            fdrec[WB_FD_SB + x] = pk_sb[x];
+        }
+        if (x == 0) {
+            fdrec[1] = J;
+            fdrec[2] = npk;
+            fdrec[3] = sh[4];
+            fdrec[4] = sh[5];
+            fdrec[0] = 1;
+        }
+        return;
+    }
     if (sh[2]) {
         // one data phase, one k-group per thread: centroid images of the committed clusters (cnew_j into a's slot, THEN
         // the compaction move) and the merged centroids of the next batch (clustering.go:37-40), in chunks of 8
@@ -3232,8 +3380,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         w->cn_stride = 4 * std::max<int64_t>(ngrp, wb_groups((int)dd) + WB_PAD_G);
         WS_ALLOC(cnew, float, 16 * w->cn_stride); // 16 images whatever WB_K is: the update kernel's centroid pieces always cover 16 chains
         ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
-        WS_ALLOC(cnewI, float, 16 * w->cn_stride);
-        ICL_HIP(ctx, hipMemsetAsync(w->cnewI, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
+        WS_ALLOC(cnewI, float, 16 * w->cn_stride + WB_FD_WORDS); // + the finish kernel's record for ward_finish_data_kernel
+        ICL_HIP(ctx, hipMemsetAsync(w->cnewI, 0, (size_t)(16 * w->cn_stride + WB_FD_WORDS) * sizeof(float), ctx->stream));
         WS_ALLOC(slot_id, int32_t, w->S);
         WS_ALLOC(id_slot, int32_t, w->M);
         WS_ALLOC(asz, int32_t, w->M);
@@ -3614,10 +3762,18 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             wx_attr = true;
         }
+        static const bool fd_split = [] { // ICL_WARD_FD=0: the express data phase stays inside the finish kernel (A/B switch)
+            const char *e = getenv("ICL_WARD_FD");
+            return !(e && e[0] == '0');
+        }();
+        int32_t *fdrec = (!lw && gen2 && fd_split && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
-                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0);
-            if (!lw && gen2) // the pair-interleaved copy of the centroids the finish kernel has just written + the block counter reset
+                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0, fdrec);
+            if (fdrec) // the express step's data phase on several CUs, the pair-interleaved copy of the new centroids, the block counter reset
+                hipLaunchKernelGGL(ward_finish_data_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, WB_FD_THREADS)), dim3(WB_FD_THREADS), 0,
+                                   ctx->stream, d, w->S, w->CT, w->Crow, w->cnew, w->cnewI, w->cn_stride, fdrec, w->st);
+            else if (!lw && gen2) // the pair-interleaved copy of the centroids the finish kernel has just written + the block counter reset
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
                                    w->cn_stride, w->cnewI, w->st);
         };
