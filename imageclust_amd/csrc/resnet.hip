@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #define ICL_MAX_LANES 4 /* forward passes in flight (ICL_EMBED_STREAMS) */
@@ -1154,32 +1155,66 @@ extern "C" int icl_embed_u8(icl_ctx *ctx, const uint8_t *img, int64_t n, int hea
     if (n == 0) return ICL_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
-    uint8_t *d_img = nullptr;
-    float *d_out = nullptr;
-    // stream the images through in slabs of at most 4096 so host-side callers never need N*150 KB of HBM at once
+    // Stream the images through in slabs of at most 4096, so host-side callers never need N*150 KB of HBM at once, with two slab
+    // buffers: a helper thread uploads slab i+1 on its own stream (pageable host memory is staged by the runtime, which keeps the
+    // calling thread busy for the whole copy) while the forward passes of slab i run -- the PCIe-inclusive rate of DESIGN.md 5.
     const int64_t slab = std::min<int64_t>(n, 4096);
-    ICL_HIP(ctx, hipMalloc((void **)&d_img, (size_t)slab * ICL_IMG_BYTES));
-    hipError_t e = hipMalloc((void **)&d_out, (size_t)slab * head * 4);
-    int rc = e == hipSuccess ? ICL_OK : icl_fail(ctx, ICL_ERR_NOMEM, "embed output buffer: %s", hipGetErrorString(e));
-    double total_ms = 0;
-    for (int64_t i = 0; rc == ICL_OK && i < n; i += slab) {
-        const int64_t cnt = std::min(slab, n - i);
-        e = hipMemcpyAsync(d_img, img + i * ICL_IMG_BYTES, (size_t)cnt * ICL_IMG_BYTES, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) {
-            rc = icl_fail(ctx, ICL_ERR_HIP, "image upload: %s", hipGetErrorString(e));
-            break;
+    const int nbuf = n > slab ? 2 : 1;
+    uint8_t *d_img[2] = {nullptr, nullptr};
+    float *d_out = nullptr;
+    hipStream_t cs = nullptr;
+    struct cleanup {
+        uint8_t **img;
+        float **out;
+        hipStream_t *cs;
+        ~cleanup()
+        {
+            for (int q = 0; q < 2; ++q)
+                if (img[q]) (void)hipFree(img[q]);
+            if (*out) (void)hipFree(*out);
+            if (*cs) (void)hipStreamDestroy(*cs);
         }
-        rc = embed_dev_locked(ctx, d_img, cnt, head, prec, d_out);
+    } cl{d_img, &d_out, &cs};
+    ICL_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (int q = 0; q < nbuf; ++q)
+        if (hipMalloc((void **)&d_img[q], (size_t)slab * ICL_IMG_BYTES) != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "embed image slab (%lld images)", (long long)slab);
+    if (hipMalloc((void **)&d_out, (size_t)slab * head * 4) != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "embed output buffer");
+    auto upload = [&](int64_t i, uint8_t *dst) -> hipError_t {
+        const int64_t cnt = std::min(slab, n - i);
+        hipError_t e = hipMemcpyAsync(dst, img + i * ICL_IMG_BYTES, (size_t)cnt * ICL_IMG_BYTES, hipMemcpyHostToDevice, cs);
+        return e == hipSuccess ? hipStreamSynchronize(cs) : e;
+    };
+    hipError_t e = upload(0, d_img[0]);
+    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "image upload: %s", hipGetErrorString(e));
+    int rc = ICL_OK;
+    double total_ms = 0;
+    int64_t k = 0;
+    for (int64_t i = 0; rc == ICL_OK && i < n; i += slab, ++k) {
+        const int64_t cnt = std::min(slab, n - i), inext = i + slab;
+        hipError_t e_up = hipSuccess;
+        std::thread up;
+        if (inext < n) {
+            uint8_t *dst = d_img[(k + 1) & 1]; // last read by slab k-1, which has finished
+            try {
+                up = std::thread([&, inext, dst] {
+                    (void)hipSetDevice(ctx->device);
+                    e_up = upload(inext, dst);
+                });
+            } catch (...) { // no thread to be had: upload in line
+                e_up = upload(inext, dst);
+            }
+        }
+        rc = embed_dev_locked(ctx, d_img[k & 1], cnt, head, prec, d_out);
         total_ms += ctx->last_embed_ms;
         if (rc == ICL_OK) {
             e = hipMemcpyAsync(out + i * head, d_out, (size_t)cnt * head * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "embedding copy-back: %s", hipGetErrorString(e));
         }
+        if (up.joinable()) up.join();
+        if (rc == ICL_OK && e_up != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "image upload: %s", hipGetErrorString(e_up));
     }
     ctx->last_embed_ms = total_ms;
-    if (d_img) (void)hipFree(d_img);
-    if (d_out) (void)hipFree(d_out);
     return rc;
 }
 

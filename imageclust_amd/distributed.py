@@ -83,17 +83,31 @@ def tile_plan(n: int, world: int):
     return plan
 
 
-def exchange_spans(rank: int, world: int, plan, my_span, recv_buffer):
-    """The one exchange of the distance build: every rank r > 0 sends its span to rank 0.  On rank 0 recv_buffer(r) returns
-    the tensor the span of rank r lands in (for the GPU path: a view of the triangle itself).  Returns the pending requests
-    (rank 0) so the caller can compute its own rows while the transfers run."""
+SPAN_CHUNK = 1 << 28  # floats per point-to-point message (1 GiB): a rank's span can exceed 2^31 elements (40 GB at world 2)
+
+
+def exchange_spans(rank: int, world: int, plan, my_span, recv_buffer, chunk: int = 0):
+    """The one exchange of the distance build: every rank r > 0 sends its span to rank 0 in messages of at most `chunk`
+    floats (default SPAN_CHUNK).  On rank 0 recv_buffer(r) returns the tensor the span of rank r lands in (for the GPU path: a
+    view of the triangle itself).  Returns the pending requests (rank 0) so the caller can compute its own rows while the
+    transfers run; messages of one peer are matched in order, peers proceed concurrently (one xGMI link each)."""
     if world <= 1:
         return []
+    chunk = int(chunk) if chunk else SPAN_CHUNK
     if rank != 0:
-        if plan[rank][3] > 0:
-            dist.send(my_span, dst=0)
+        cnt = plan[rank][3]
+        for off in range(0, cnt, chunk):
+            dist.send(my_span[off:min(off + chunk, cnt)], dst=0)
         return []
-    return [dist.irecv(recv_buffer(r), src=r) for r in range(1, world) if plan[r][3] > 0]
+    reqs = []
+    bufs = {r: recv_buffer(r) for r in range(1, world) if plan[r][3] > 0}
+    nmsg = max((plan[r][3] + chunk - 1) // chunk for r in range(world))
+    for m in range(nmsg):  # round-robin over the peers so that every link has a receive posted from the start
+        for r, buf in bufs.items():
+            off = m * chunk
+            if off < plan[r][3]:
+                reqs.append(dist.irecv(buf[off:min(off + chunk, plan[r][3])], src=r))
+    return reqs
 
 
 def cluster_with_distributed_tiles(ctx, E_full: torch.Tensor, min_size: int, max_size: int, rank: int, world: int, update=0, staged=False):

@@ -94,7 +94,7 @@ def test_tile_plan_covers_the_triangle_with_balanced_area():
                 assert plan[0][1] - plan[0][0] > 2 * (plan[-1][1] - plan[-1][0]) or w == 1
 
 
-def _span_worker(rank, world, port, n, q):
+def _span_worker(rank, world, port, n, q, chunk=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     D.init("gloo", rank, world)
@@ -111,23 +111,23 @@ def _span_worker(rank, world, port, n, q):
     if rank == 0:
         tri = torch.zeros(sum(p[3] for p in plan), dtype=torch.float32)
         tri[off:off + cnt] = mine
-        reqs = D.exchange_spans(rank, world, plan, None, lambda r: tri[plan[r][2]:plan[r][2] + plan[r][3]])
+        reqs = D.exchange_spans(rank, world, plan, None, lambda r: tri[plan[r][2]:plan[r][2] + plan[r][3]], chunk)
         for rq in reqs:
             rq.wait()
         ok = bool(torch.equal(tri, torch.from_numpy(_pack_rows(full, 0, n))))  # rank 0 now holds exactly the packed triangle
     else:
-        D.exchange_spans(rank, world, plan, mine, None)
+        D.exchange_spans(rank, world, plan, mine, None, chunk)
     D.barrier()
     q.put((rank, ok))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 300), (3, 700), (2, 129)])
-def test_span_exchange_assembles_the_packed_triangle_gloo(world, n):
+@pytest.mark.parametrize("world,n,chunk", [(2, 300, 0), (3, 700, 0), (2, 129, 0), (3, 700, 4099), (2, 300, 1)])
+def test_span_exchange_assembles_the_packed_triangle_gloo(world, n, chunk):  # chunk > 0: spans cut into several messages
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_span_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_span_worker, args=(r, world, port, n, q, chunk)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

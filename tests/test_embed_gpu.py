@@ -138,6 +138,22 @@ def test_embed_edge_cases(ctx, L):
     c2.close()
 
 
+def test_host_buffers_several_slabs_equal_resident_images(ctx, L):
+    """icl_embed_u8 (host pointers: 4096-image slabs, the next slab uploaded by a helper thread while this one is embedded)
+    returns exactly what icl_embed_u8_dev returns on the same images resident in HBM -- ragged last slab included."""
+    import torch
+
+    n = 2 * 4096 + 37
+    imgs = torch.empty(n * L.IMG_BYTES, dtype=torch.uint8, device="cuda")
+    ctx.synth_images_dev(99, 0, n, L.SYNTH_STRUCTURED, imgs.data_ptr())
+    ctx.sync()  # the engine's stream is not torch's
+    E = torch.empty((n, 2048), dtype=torch.float32, device="cuda")
+    ctx.embed_u8_dev(imgs.data_ptr(), n, E.data_ptr(), 2048, L.PREC_BF16)
+    out = ctx.embed_u8(imgs.cpu().numpy(), L.HEAD_POOLED, L.PREC_BF16)
+    assert out.shape == (n, 2048) and np.isfinite(out).all()
+    assert np.array_equal(out, E.cpu().numpy())
+
+
 def test_reference_style_api(ctx, L, tmp_path):
     from imageclust_amd import embeddings as EM
 
