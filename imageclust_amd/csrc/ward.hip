@@ -2117,24 +2117,68 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     if (done || nb <= 0) return;
     const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
-    int pa[WB_K], pb[WB_K], psc[WB_K];
-#pragma unroll
-    for (int j = 0; j < WB_K; ++j) {
-        pa[j] = st->B.a[j];
-        pb[j] = st->B.b[j];
-        psc[j] = st->B.sa[j] + st->B.sb[j];
+    // the batch's picks (members a_j, b_j and the merged size) live in LDS: 48 wave-uniform values held in SGPRs for the whole
+    // kernel were spilled to VGPR lanes and read back 286 times in every block's prologue
+    __shared__ int pa[WB_K], pb[WB_K], psc[WB_K];
+    if (threadIdx.x < WB_K) {
+        pa[threadIdx.x] = st->B.a[threadIdx.x];
+        pb[threadIdx.x] = st->B.b[threadIdx.x];
+        psc[threadIdx.x] = st->B.sa[threadIdx.x] + st->B.sb[threadIdx.x];
     }
+    __syncthreads();
     // PERSISTENT main workgroups: the grid holds at most one per CU; each draws 64-slot blocks from a device-wide counter
     // (reset every step by ward_interleave_kernel) until the live range is exhausted.  The per-launch state above is read
     // once per workgroup instead of once per block, there is no workgroup launch per block, and workgroups that start late
     // (their CU ran a spare / preselection workgroup first) simply draw fewer blocks.
-    __shared__ int cur_blk;
     __shared__ int wexit_stage[WX_CW];
-    for (bool first = true;; first = false) {
-    __syncthreads(); // the previous block's ring reads and its cur_blk reads are done
-    if (threadIdx.x == 0) cur_blk = virt ? (first ? 0 : -1) : atomicAdd(&st->B.blk_next, 1);
-    __syncthreads();
-    const int64_t mblk = cur_blk;
+    // The NEXT block is drawn and its per-slot state fetched while the current one is being computed: chain wave 0 (whose vmcnt
+    // is otherwise unused) issues the counter atomic, the slot_id load, the dependent asz load and the LDS hand-over at four
+    // points of the stage loop, so each wait finds its data already there.  Drawn on the spot, the same chain cost every block
+    // ~5 us (two workgroup barriers around a device atomic) + ~4 us of dependent loads: a quarter of the block's 46 us.
+    static_assert(WX_NS == 1, "the next-block hand-over holds one set of 64 slots");
+    __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_dirty[2][64];
+    int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_dirty = 0; // chain wave 0 only
+    auto pf_advance = [&](const int upto, const int par) {
+        if (pf_done < 1 && upto >= 1) { // draw
+            pf_raw = lane == 0 ? atomicAdd(&st->B.blk_next, 1) : 0;
+            pf_done = 1;
+        }
+        if (pf_done < 2 && upto >= 2) { // the drawn block's clusters; which of its columns are stale
+            int r = pf_raw;
+            asm volatile("" : "+v"(r)); // the atomic's result is first looked at HERE (hipcc otherwise hoists the readfirstlane, and with it the wait, next to the atomic)
+            pf_blk = __builtin_amdgcn_readfirstlane(r);
+            const bool on = (int64_t)pf_blk * 64 < nlive;
+            const int sl = pf_blk * 64 + lane;
+            pf_dirty = 0;
+            const int nd = on ? dirty_n0 : 0;
+            for (int z = 0; z < nd; ++z) pf_dirty |= __shfl(dirty_s0, z, 64) == sl;
+            pf_xr = on ? slot_id[sl] : -1; // last: a loop after the load would wait for it at once
+            pf_done = 2;
+        }
+        if (pf_done < 3 && upto >= 3) { // their sizes
+            pf_x = ((int64_t)pf_blk * 64 + lane < nlive) ? pf_xr : -1;
+            pf_sx = pf_x >= 0 ? asz[pf_x] : 0;
+            pf_done = 3;
+        }
+        if (pf_done < 4 && upto >= 4) { // hand over
+            if (lane == 0) nx_blk[par] = pf_blk;
+            nx_x[par][lane] = pf_x;
+            nx_sx[par][lane] = pf_sx;
+            nx_dirty[par][lane] = pf_dirty;
+            pf_done = 4;
+        }
+    };
+    if (wave == 0 && !virt) pf_advance(4, 0); // the first block: nothing to hide behind
+    int rp = 0;       // ring slot of the current block's stage 0: the ring runs on across blocks
+    bool pre = false; // the current block's first WX_R-1 stages were requested during the previous block's last stages
+    for (int blk_it = 0;; ++blk_it) {
+    const int par = blk_it & 1;
+    // (a raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. for the epilogue's scattered stores and atomics and for the
+    // ring stages the loaders have already requested for this block -- 3.5 + 4.8 us per block at the two barriers of this loop)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the previous block's ring reads are done; the hand-over of this block is visible
+    const int64_t mblk = virt ? (blk_it == 0 ? 0 : -1) : __builtin_amdgcn_readfirstlane(nx_blk[par]); // (an LDS read: tell hipcc it is wave-uniform)
+    rp = __builtin_amdgcn_readfirstlane(rp);
+    pf_done = 0;
     // A workgroup owns WX_NS sets of 64 consecutive slots (the virtual-slot workgroup: one set).  The sets share every
     // centroid read and the per-launch overhead; a set beyond the live range is simply inactive.
     if (mblk < 0 || (!virt && mblk * (64 * WX_NS) >= nlive)) break;
@@ -2152,9 +2196,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         set_on[u] = virt ? u == 0 : (mblk * WX_NS + u) * 64 < nlive; // wave-uniform
         // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
         // streams its centroid from the row-major copy instead and the column is re-made on the way
-        dirty_lane[u] = false;
-        const int nd = (virt || !set_on[u]) ? 0 : dirty_n0;
-        for (int z = 0; z < nd; ++z) dirty_lane[u] |= __shfl(dirty_s0, z, 64) == (int)slot[u];
+        dirty_lane[u] = !virt && set_on[u] && nx_dirty[par][lane] != 0;
         any_dirty |= __any(dirty_lane[u]);
     }
     const int nstage = (dqp + WX_SG - 1) / WX_SG; // the CT4 columns and the centroid images are zero-padded past dqp: (0-0)^2 adds +0
@@ -2176,19 +2218,17 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         const int ch = idx / WX_SG, g = idx % WX_SG;
         return reinterpret_cast<const char *>(cnewK) + ((int64_t)ch * cn_stride + ((int64_t)stage * WX_SG + g) * 4) * 4;
     };
-    auto issue = [&](int stage) { // this loader wave's pieces of one stage: 64 lanes x 16 B each, lane-linear in the ring
+    auto issue = [&](int stage, int phase, int64_t slot_l, bool dirty_l) { // this loader wave's pieces of one stage (of this block, or of the next one: phase = its ring slot of stage 0): 64 lanes x 16 B each, lane-linear in the ring
         const int g0 = stage * WX_SG + pj * WX_XOPS;
-        const unsigned sbase = ring_base + (unsigned)((stage % WX_R) * WX_STAGE_F4 * 16);
-#pragma unroll
-        for (int u = 0; u < WX_NS; ++u) {
-            if (!set_on[u]) continue; // an inactive set's ring area is never read
-            const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot[u] * 16;
+        const unsigned sbase = ring_base + (unsigned)(((phase + stage) % WX_R) * WX_STAGE_F4 * 16);
+        {
+            const int64_t voff = virt ? (int64_t)(lane < WB_K ? lane : 0) * cn_stride * 4 : slot_l * 16;
 #pragma unroll
             for (int q = 0; q < WX_XOPS; ++q) {
                 const int g = g0 + q;
                 const char *src = ctb + (int64_t)g * row_bytes + voff;
-                if (dirty_lane[u] && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot[u] * d + (int64_t)g * 4) * 4;
-                glds16_asm(src, sbase + (unsigned)((u * WX_SG + pj * WX_XOPS + q) * 1024));
+                if (dirty_l && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot_l * d + (int64_t)g * 4) * 4;
+                glds16_asm(src, sbase + (unsigned)((pj * WX_XOPS + q) * 1024));
             }
         }
 #pragma unroll
@@ -2197,21 +2237,21 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     };
     const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
     const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
-    if (loader && do_load)
-        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i);
+    // cross-block ring: with enough stages per block the loaders request the NEXT block's first WX_R-1 stages while this block's
+    // last ones are computed (its index and dirty columns are handed over by then), so a block does not start on an empty ring
+    const bool xblk = !virt && !(WX_PRUNE && prune_beta >= 1.0f) && nstage >= 8 && do_load;
+    const int iD = xblk ? (3 * nstage) / 4 - 1 : nstage - 1; // the stage after whose barrier chain wave 0 hands the next block over
+    if (loader && do_load && !pre)
+        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i, rp, slot[0], dirty_lane[0]);
     // ---- part 2: which rows does this lane's cluster take part in?
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) {
         if (virt) {
             x[u] = (u == 0 && lane < nb) ? (int)(n + t + lane) : -1;
-            sx[u] = 0;
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j)
-                if (lane == j) sx[u] = psc[j];
+            sx[u] = lane < WB_K ? psc[lane] : 0;
         } else {
-            const int xraw = set_on[u] ? slot_id[slot[u]] : -1;
-            x[u] = slot[u] < nlive ? xraw : -1;
-            sx[u] = x[u] >= 0 ? asz[x[u]] : 0;
+            x[u] = nx_x[par][lane];
+            sx[u] = nx_sx[par][lane];
         }
         okmask[u] = 0;
         bool alive = x[u] >= 0 && sx[u] > 0;
@@ -2233,6 +2273,9 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         // nothing to compute here (the requested stages must land before the ring is reused), but a stale column must not
         // outlive this step's dirty list
         if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0 && !virt) pf_advance(4, par ^ 1);
+        rp = (rp + (WX_R - 1 < nstage ? WX_R - 1 : nstage)) % WX_R; // the stages requested for this block were never consumed: the next block's ring starts behind them
+        pre = false;
 #pragma unroll
         for (int u = 0; u < WX_NS; ++u) {
             unsigned long long dm = __ballot(dirty_lane[u]);
@@ -2307,7 +2350,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         }
     };
     auto consume = [&](int stage) {
-        const float4 *sb_ = wb_lds + (stage % WX_R) * WX_STAGE_F4;
+        const float4 *sb_ = wb_lds + ((rp + stage) % WX_R) * WX_STAGE_F4;
         const float4 *xr = sb_ + lane;
         // wave-uniform addresses: broadcast reads.  WX_CPW == 2: this wave's pair, [k-group][2 halves]; else [chain][k-group]
         const float4 *ca = sb_ + WX_NS * WX_SG * 64 + (WX_CPW == 2 ? (jA >> 1) * (2 * WX_SG) : jA * WX_SG);
@@ -2334,25 +2377,22 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             if (j < nb) vlast = fmaxf(vlast, st->B.val[j]);
         tau = prune_beta * vlast;
         if (chain) {
-            int sa_ = psc[0], sb_ = psc[0];
-#pragma unroll
-            for (int q = 1; q < WB_K; ++q) {
-                if (q == jA) sa_ = psc[q];
-                if (q == jB) sb_ = psc[q];
-            }
+            const int sa_ = psc[jA], sb_ = psc[jB < WB_K ? jB : 0];
             if ((okmask[0] >> jA) & 1u) facA = (float)((int64_t)sx[0] * sa_) / (float)(sx[0] + sa_);
             if (WX_CPW == 2 && jB < nb && ((okmask[0] >> jB) & 1u)) facB = (float)((int64_t)sx[0] * sb_) / (float)(sx[0] + sb_);
         }
     }
     if (threadIdx.x < WX_CW) wexit_stage[threadIdx.x] = (prune && threadIdx.x * WX_CPW < nb) ? (1 << 30) : ((prune ? -1 : (1 << 30))); // idle chain waves count as stopped
     bool wstopped = false;
-    __syncthreads();
+    int nxt_blk = -1;
+    bool nxt_on = false, nxt_dirty = false; // the next block, once handed over (cross-block ring)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // wexit_stage is set
     for (int i = 0; i < nstage; ++i) {
         if (loader) {
             // stage i has landed once at most the WX_R-2 younger stages are outstanding (in the tail nothing new is issued:
             // wait for everything, those stages have been in flight all along).  A workgroup with one live set issues fewer
             // pieces per stage, so its count is smaller.
-            if (i + WX_R - 2 < nstage) {
+            if (i + WX_R - 2 < nstage || nxt_on) { // (nxt_on: the younger stages in flight are the next block's)
                 if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_NS * WX_XOPS + WX_COPS)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_XOPS + WX_COPS)) : "memory");
             } else
@@ -2361,6 +2401,12 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of stage i-1 have returned before its ring slot is refilled
         }
         __builtin_amdgcn_s_barrier();
+        if (wave == 0 && !virt) pf_advance(i == 0 ? 1 : i == (nstage >> 2) ? 2 : i == (nstage >> 1) ? 3 : i == iD ? 4 : 0, par ^ 1);
+        if (xblk && i == iD + 1) { // the hand-over was written before this barrier: every wave reads the same answer
+            nxt_blk = __builtin_amdgcn_readfirstlane(nx_blk[par ^ 1]);
+            nxt_on = (int64_t)nxt_blk * 64 < nlive;
+            nxt_dirty = nxt_on && nx_dirty[par ^ 1][lane] != 0;
+        }
         if (prune && i > 0) { // every chain wave stopped during stage <= i-1: nothing left to compute, stop loading too
             int stopped = 0;
 #pragma unroll
@@ -2371,7 +2417,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             if (any_dirty && i * WX_SG >= 2 * WB_SG) { // re-make the dirty columns (beyond the groups the finish kernel re-made) from the stage that has just landed (rare)
 #pragma unroll
                 for (int u = 0; u < WX_NS; ++u) {
-                    const float4 *xr = wb_lds + (i % WX_R) * WX_STAGE_F4 + u * WX_SG * 64 + lane;
+                    const float4 *xr = wb_lds + ((rp + i) % WX_R) * WX_STAGE_F4 + u * WX_SG * 64 + lane;
 #pragma unroll
                     for (int q = 0; q < WX_XOPS; ++q) {
                         const int g = i * WX_SG + pj * WX_XOPS + q;
@@ -2379,7 +2425,10 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
                     }
                 }
             }
-            if (i + WX_R - 1 < nstage && do_load) issue(i + WX_R - 1); // into the slot stage i-1 was read from: every chain wave is past this barrier
+            if (i + WX_R - 1 < nstage) {
+                if (do_load) issue(i + WX_R - 1, rp, slot[0], dirty_lane[0]); // into the slot stage i-1 was read from: every chain wave is past this barrier
+            } else if (nxt_on) // the ring runs on into the next block (its stage 0 sits in slot rp + nstage)
+                issue(i + WX_R - 1 - nstage, rp + nstage, (int64_t)nxt_blk * 64 + lane, nxt_dirty);
         } else if (chain && do_chain && !wstopped) {
             consume(i);
             if (prune) {
@@ -2392,7 +2441,10 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             }
         }
     }
-    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the ring is reused / the LDS released
+    if (loader && !nxt_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the ring is reused / the LDS released (with nxt_on what is in flight belongs to the next block, which waits for it stage by stage)
+    if (wave == 0 && !virt) pf_advance(4, par ^ 1); // few stages (small D) or an early stop: finish the hand-over now
+    rp = (rp + nstage) % WX_R;
+    pre = nxt_on;
     if (!chain) continue;
     if (prune && lane == 0) {
         atomicAdd(&st->B.chain_waves, 1ull);
@@ -2402,16 +2454,10 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     for (int cc = 0; cc < WX_CPW; ++cc) {
         const int j = jA + cc;
         if (j >= nb) break;
-        int sc = psc[0];
-#pragma unroll
-        for (int q = 1; q < WB_K; ++q)
-            if (j == q) sc = psc[q];
+        const int sc = psc[j];
         const int64_t c = n + t + j;
         const int64_t ro = rowoff[c];
-        int mark = pa[0]; // a_j: dead once c_j exists
-#pragma unroll
-        for (int q = 1; q < WB_K; ++q)
-            if (j == q) mark = pa[q];
+        const int mark = pa[j]; // a_j: dead once c_j exists
         unsigned long long key = ~0ull, key2 = ~0ull;
 #pragma unroll
         for (int u = 0; u < WX_NS; ++u) {
