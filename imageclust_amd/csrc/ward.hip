@@ -2120,10 +2120,12 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     // the batch's picks (members a_j, b_j and the merged size) live in LDS: 48 wave-uniform values held in SGPRs for the whole
     // kernel were spilled to VGPR lanes and read back 286 times in every block's prologue
     __shared__ int pa[WB_K], pb[WB_K], psc[WB_K];
+    __shared__ int64_t ro_l[WB_K]; // where the rows being created start in the triangle: read once per launch, not once per block and chain (a dependent global load in front of every chain's stores)
     if (threadIdx.x < WB_K) {
         pa[threadIdx.x] = st->B.a[threadIdx.x];
         pb[threadIdx.x] = st->B.b[threadIdx.x];
         psc[threadIdx.x] = st->B.sa[threadIdx.x] + st->B.sb[threadIdx.x];
+        ro_l[threadIdx.x] = (int)threadIdx.x < nb ? rowoff[n + t + threadIdx.x] : 0;
     }
     __syncthreads();
     // PERSISTENT main workgroups: the grid holds at most one per CU; each draws 64-slot blocks from a device-wide counter
@@ -2455,8 +2457,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         const int j = jA + cc;
         if (j >= nb) break;
         const int sc = psc[j];
-        const int64_t c = n + t + j;
-        const int64_t ro = rowoff[c];
+        const int64_t ro = ro_l[j];
         const int mark = pa[j]; // a_j: dead once c_j exists
         unsigned long long key = ~0ull, key2 = ~0ull;
 #pragma unroll
