@@ -2622,7 +2622,7 @@ struct wb_map { // a tiny associative array spread over the lanes of a wave
     {
         const unsigned long long m = __ballot(key == q);
         if (!m) return false;
-        out = __shfl(val, __ffsll((long long)m) - 1, 64);
+        out = __builtin_amdgcn_readlane(val, __ffsll((long long)m) - 1); // a wave-uniform lane index: v_readlane, not a trip through the LDS crossbar
         return true;
     }
     __device__ __forceinline__ void set(int q, int v, int &cnt, int lane) // every copy of the key is updated
