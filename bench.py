@@ -275,8 +275,8 @@ def main():
         # committed under profiles/ and quoted here.
         traffic = traffic_upd = pmc_file = None
         traffic_note = ""
-        try:  # profiles/r02b_pmc_traffic.json: scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script at the default workload)
-            pmc_file = "r02b_pmc_traffic.json"
+        try:  # profiles/r02c_pmc_traffic.json: scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script at the default workload)
+            pmc_file = "r02c_pmc_traffic.json"
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
             c_a, c_b = pmc["conv_igemm_kernel<BF16, 128, false, 2, true>"], pmc["conv_igemm_kernel<BF16, 128, true, 2, true>"]

@@ -2153,7 +2153,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             const int sl = pf_blk * 64 + lane;
             pf_dirty = 0;
             const int nd = on ? dirty_n0 : 0;
-            for (int z = 0; z < nd; ++z) pf_dirty |= __shfl(dirty_s0, z, 64) == sl;
+            for (int z = 0; z < nd; ++z) pf_dirty |= __builtin_amdgcn_readlane(dirty_s0, z) == sl;
             pf_xr = on ? slot_id[sl] : -1; // last: a loop after the load would wait for it at once
             pf_done = 2;
         }
@@ -2830,7 +2830,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 else if (lane >= WB_K && lane < WB_K + np) myid = ls.B.pre_nn[lane - WB_K];
                 int gs = myid >= 0 ? id_slot[myid] : -1;
                 for (int m = 0; m < 4 * WB_K; ++m) { // entries touched by this kernel come from the lane map
-                    const int mk = __shfl(idm.key, m, 64), mv = __shfl(idm.val, m, 64);
+                    const int mk = __builtin_amdgcn_readlane(idm.key, m), mv = __builtin_amdgcn_readlane(idm.val, m); // (wave-uniform lane index)
                     if (mk >= 0 && mk == myid) gs = mv;
                 }
                 // Where does each pick member's centroid come from?  Normally its slot's row; if the slot is written by
@@ -2842,7 +2842,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 {
                     int last_r = -1;
                     for (int r = 0; r < 2 * WB_K; ++r) {
-                        const int o = __shfl(rec, r, 64);
+                        const int o = __builtin_amdgcn_readlane(rec, r);
                         if (o >= 0 && o == gs) last_r = r; // program order: the last record is the slot's final content
                         if (o >= 0 && o == frm && lane < WB_K && r <= 2 * lane) need = true; // a move whose source was written earlier
                     }
