@@ -277,6 +277,14 @@ def test_large_n_tight_constraints(ctx):
     same_as_fast_oracle(ctx, WC.mog(20000, 8, 3), 5, 6)
 
 
+def test_large_n_wide_rows_workgroups_run_several_blocks(ctx):
+    """N=26 000, D=1024: 407 blocks of 64 slots for 256 persistent workgroups and 8 ring stages per block, i.e. the update
+    kernel's next-block hand-over and the ring that runs on across blocks (both need >= 8 stages and a second block) are on
+    the path for the first ~9 000 merges, against the oracle: ids, member order, merge log, every merge value."""
+    f = same_as_fast_oracle(ctx, WC.mog(26000, 1024, 5), 5, 50)
+    assert f["merges"] == 26000 - O.calc_optimal_clusters(26000, 5, 50)[0]
+
+
 def test_config2_full_size_properties_100k(ctx):
     """BASELINE.json's metric size: N=100 000, D=2048, min=5 max=50 (k=11 000, 89 000 merges, 80 GB triangle).  No CPU
     oracle reaches this size: size-independent properties + idempotence."""
