@@ -1985,8 +1985,13 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
         reinterpret_cast<float2 *>(cnewI)[p * cn_stride + k] = v;
         return;
     }
-    if (i >= (d >> 2)) return;
-    const int g = (int)i;
+    // threads [0, d/4): chunk 0 (commits / picks 0..7) of k-group i; threads [FDQ, FDQ + d/4): chunk 1 (8..15) -- the chunks are
+    // independent (the finish kernel sends a batch whose picks read an old cnew row of the other chunk down the general path)
+    const int64_t FDQ = ((int64_t)(d >> 2) + WB_FD_THREADS - 1) / WB_FD_THREADS * WB_FD_THREADS;
+    const int my_chunk = i >= FDQ ? 1 : 0;
+    const int64_t gi = i - (my_chunk ? FDQ : 0);
+    if (gi >= (d >> 2)) return;
+    const int g = (int)gi;
     const int J = fdrec[1], np = fdrec[2];
     const unsigned long long deadm = ((unsigned long long)(unsigned)fdrec[4] << 32) | (unsigned)fdrec[3]; // records overwritten later
     const int32_t *cm_slot_a = fdrec + WB_FD_SLOT_A, *cm_from = fdrec + WB_FD_FROM, *cm_to = fdrec + WB_FD_TO;
@@ -2073,8 +2078,8 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
 #undef WB_REP16
     };
     const int cmax = J > np ? J : np;
-    chunk(0);
-    if (WB_K > 8 && 8 < cmax) chunk(8);
+    if (my_chunk == 0) chunk(0);
+    else if (WB_K > 8 && 8 < cmax) chunk(8);
     static_assert(WB_K <= 16, "two chunks of 8 commits / picks");
 }
 
@@ -2852,7 +2857,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         const int j = last_r >> 1;
                         if (!(last_r & 1)) { // the cluster created by commit j: its centroid is the OLD cnew row j
                             srcsel = -1 - j;
-                            if (pick >= 8 && j < 8) need = true; // the second chunk runs after the first rewrote rows 0..7
+                            if ((pick >= 8) != (j >= 8)) need = true; // the two chunks of 8 picks run on different threads (ward_finish_data_kernel): neither may read an old cnew row the other one rewrites
                         } else {             // moved by commit j from slot frm_j
                             const int fj = __shfl(frm, j, 64);
                             srcsel = fj;
