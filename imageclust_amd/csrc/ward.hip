@@ -2302,11 +2302,9 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     float sA[WX_NS], sB[WX_NS];
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) sA[u] = sB[u] = 0.0f;
-    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
     f2 sP[WX_NS]; // WX_CPW == 2: {sA, sB} of each slot set as one packed register pair
 #pragma unroll
     for (int u = 0; u < WX_NS; ++u) sP[u] = f2{0.0f, 0.0f};
-    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times
     // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times.
     // (Measured and dropped: an explicit two-register-set software pipeline across quarters -- reads of quarter q+1 issued before
     // quarter q is computed -- is SLOWER than hipcc's own interleaving of the same reads: 54 vs 45 us per block.)
