@@ -1,5 +1,7 @@
 """GPU parity tests of the Ward engine (imageclust_amd/csrc/ward.hip) against the CPU oracle, called through the
 C-ABI exactly as the reference's callers would use internal/clustering (clustering.go).  Bar: BIT-EXACT."""
+import os
+
 import numpy as np
 import pytest
 
@@ -336,6 +338,29 @@ def test_config2_full_size_properties_100k(ctx):
     # idempotence
     cid2, rank2, nc2 = ctx.cluster_dev(E.data_ptr(), n, d, 5, 50)
     assert nc2 == nc and np.array_equal(cid, cid2) and np.array_equal(rank, rank2) and np.array_equal(ctx.last_merges(), m)
+
+
+def test_config2_full_size_two_pipelines_agree_100k(ctx):
+    """N=100 000, D=2048 again, this time as a parity statement: the batched pipeline (up to 16 merges per step, the shipped
+    path) and the one-merge-per-step pipeline (ICL_WARD_BATCH=0: other update / finish / preselection kernels, the structure
+    whose equality with the oracle is tested up to N=45 000) must produce the same merge log, merge values, ids and member order.
+    The switch is read once per process, so the slow pipeline runs in a child."""
+    import json
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    from tests import ward_pipeline_child as C
+
+    args = (100000, 2048, 20250218, 5, 50)
+    mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
+    env = dict(os.environ, ICL_WARD_BATCH="0")
+    p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), *map(str, args)], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    other = json.loads(p.stdout.strip().splitlines()[-1])
+    assert other["E"] == mine["E"], "the two processes did not cluster the same input"
+    assert mine["n_merges"] == 89000
+    assert other == mine
 
 
 def test_context_reuse_different_shapes(ctx):

@@ -1,0 +1,36 @@
+"""Child process of test_ward_gpu.py::test_config2_full_size_two_pipelines_agree_100k: clusters the same synthetic E with
+whatever ICL_WARD_* switches the parent put into the environment (they are read once per process) and prints digests."""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from imageclust_amd import _lib  # noqa: E402
+
+
+def make_E(n, d, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    cen = torch.randn((n // 20, d), generator=g, device="cuda")
+    lab = torch.randint(0, n // 20, (n,), generator=g, device="cuda")
+    E = (cen[lab] + 0.1 * torch.randn((n, d), generator=g, device="cuda")).contiguous()
+    torch.cuda.synchronize()
+    return E
+
+
+def digests(ctx, E, mn, mx):
+    n, d = E.shape
+    cid, rank, nc = ctx.cluster_dev(E.data_ptr(), n, d, mn, mx)
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return {"n_clusters": int(nc), "merges": h(ctx.last_merges()), "values": h(ctx.last_merge_values()), "cid": h(cid), "rank": h(rank),
+            "E": h(E[:: max(1, n // 64)].cpu().numpy()), "n_merges": int(len(ctx.last_merges()))}
+
+
+if __name__ == "__main__":
+    n, d, seed, mn, mx = (int(x) for x in sys.argv[1:6])
+    ctx = _lib.Context(0)
+    print(json.dumps(digests(ctx, make_E(n, d, seed), mn, mx)))
