@@ -340,6 +340,27 @@ def test_config2_full_size_properties_100k(ctx):
     assert nc2 == nc and np.array_equal(cid, cid2) and np.array_equal(rank, rank2) and np.array_equal(ctx.last_merges(), m)
 
 
+def test_one_merge_per_step_pipeline_against_oracle_large_n(tmp_path):
+    """The one-merge-per-step pipeline (ICL_WARD_BATCH=0, read once per process: child) on its own against the oracle at
+    N=24 000 (creation ids past 40 960): it is the second witness of the 100 000-image test below."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    E = WC.mog(24000, 16, 1)
+    np.save(tmp_path / "E.npy", E)
+    f = O.cluster_fast(E, 5, 50, lazy_ban=False)
+    env = dict(os.environ, ICL_WARD_BATCH="0")
+    p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), "--npy", str(tmp_path / "E.npy"), str(tmp_path / "out.npz"), "5", "50"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = np.load(tmp_path / "out.npz")
+    assert f["ok"] and len(r["merges"]) == f["merges"] == 21360
+    assert np.array_equal(r["merges"], f["log"][:, 2:4].astype(np.int32))
+    assert np.array_equal(r["values"].view(np.uint32), f["vals"].view(np.uint32))
+    assert np.array_equal(r["cid"], f["cluster_id"]) and np.array_equal(r["rank"], f["member_rank"]) and int(r["nc"]) == f["n_clusters"]
+
+
 def test_config2_full_size_two_pipelines_agree_100k(ctx):
     """N=100 000, D=2048 again, this time as a parity statement: the batched pipeline (up to 16 merges per step, the shipped
     path) and the one-merge-per-step pipeline (ICL_WARD_BATCH=0: other update / finish / preselection kernels, the structure

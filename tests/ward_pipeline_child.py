@@ -31,6 +31,12 @@ def digests(ctx, E, mn, mx):
 
 
 if __name__ == "__main__":
-    n, d, seed, mn, mx = (int(x) for x in sys.argv[1:6])
     ctx = _lib.Context(0)
-    print(json.dumps(digests(ctx, make_E(n, d, seed), mn, mx)))
+    if sys.argv[1] == "--npy":  # E from a file, results into an npz: small cases the parent compares with the oracle
+        E = np.load(sys.argv[2])
+        mn, mx = int(sys.argv[4]), int(sys.argv[5])
+        cid, rank, nc = ctx.cluster(E, mn, mx)
+        np.savez(sys.argv[3], cid=cid, rank=rank, nc=nc, merges=ctx.last_merges(), values=ctx.last_merge_values())
+    else:
+        n, d, seed, mn, mx = (int(x) for x in sys.argv[1:6])
+        print(json.dumps(digests(ctx, make_E(n, d, seed), mn, mx)))
