@@ -2144,10 +2144,11 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     // ~5 us (two workgroup barriers around a device atomic) + ~4 us of dependent loads: a quarter of the block's 46 us.
     static_assert(WX_NS == 1, "the next-block hand-over holds one set of 64 slots");
     __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_dirty[2][64];
+    const int nmain = (int)gridDim.x - (WB_R + 2); // persistent main workgroups
     int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_dirty = 0; // chain wave 0 only
     auto pf_advance = [&](const int upto, const int par) {
-        if (pf_done < 1 && upto >= 1) { // draw
-            pf_raw = lane == 0 ? atomicAdd(&st->B.blk_next, 1) : 0;
+        if (pf_done < 1 && upto >= 1) { // draw (blocks 0 .. nmain-1 are the workgroups' first blocks: the counter hands out the rest)
+            pf_raw = lane == 0 ? nmain + atomicAdd(&st->B.blk_next, 1) : 0;
             pf_done = 1;
         }
         if (pf_done < 2 && upto >= 2) { // the drawn block's clusters; which of its columns are stale
@@ -2175,7 +2176,11 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             pf_done = 4;
         }
     };
-    if (wave == 0 && !virt) pf_advance(4, 0); // the first block: nothing to hide behind
+    if (wave == 0 && !virt) { // the first block is the workgroup's own index (no trip to the counter); its state: nothing to hide the loads behind
+        pf_raw = (int)blockIdx.x - (WB_R + 2);
+        pf_done = 1;
+        pf_advance(4, 0);
+    }
     int rp = 0;       // ring slot of the current block's stage 0: the ring runs on across blocks
     bool pre = false; // the current block's first WX_R-1 stages were requested during the previous block's last stages
     for (int blk_it = 0;; ++blk_it) {
