@@ -345,19 +345,21 @@ static constexpr size_t conv_lds_bytes(int nstages = 2)
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restrict__ img, const conv_args p)
 {
+    // PERSISTENT workgroups (the grid holds as many as fit the CUs): the 64 x 192 weights are brought into LDS once per
+    // workgroup, not once per 8x16 tile (25 088 tiles per batch of 256: 0.6 GB of L2 -> LDS traffic and a DMA round trip in front
+    // of every tile), and the next tile's input patch is fetched into registers while this tile's MFMAs run.
     typedef typename T::elem elem;
     constexpr int BN = 64;
     constexpr int NKS = STEM_K / T::BK;            // k-steps: 3 (bf16) or 6 (f32)
     constexpr int WST = BN * CV_ROWB;              // bytes of one weight k-step image
     constexpr int XST = CV_BM * CV_ROWB;
     constexpr int PATCH = STEM_PH * STEM_PW + 16;  // + slack: chunk reads run up to 11 bytes past a row's last pixel
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [NKS weight steps][2 activation buffers][patch]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [NKS weight steps][2 activation buffers][patch][fp32 epilogue tile]
     unsigned char *patch = smem + NKS * WST + 2 * XST;
+    unsigned char *ep_smem = smem + ((NKS * WST + 2 * XST + PATCH + 15) & ~15);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 1, wn = wid >> 1;
-    const int tx = blockIdx.x % 7, ty = (blockIdx.x / 7) % 14;
-    const int64_t b = blockIdx.x / 98;
-    const int64_t m0 = (b * 112 + ty * 8) * 112 + tx * 16;
+    const int ntiles = p.gx;
     const elem *Wg = (const elem *)p.Wt;
     // all weights (64 x 192) by LDS-DMA, once
     {
@@ -371,33 +373,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
                                                  (lptr_t)(smem + j * WST + (wid * 16 + i * 8) * CV_ROWB), 16, 0, 0);
             }
     }
-    // input patch: rows iy = ty*16-3 .. +20, byte columns (tx*32-3)*3 .. ; zero outside the image.  The first byte
+    // input patch of a tile: rows iy = ty*16-3 .. +20, byte columns (tx*32-3)*3 .. ; zero outside the image.  The first byte
     // column is 3 mod 4 for every tile (tx*96 - 9), rows are 672 bytes and images 150528 bytes apart, so the patch is
     // fetched as ALIGNED dwords from byte column bx0-3 on (a dword is entirely inside or outside the image) and the
     // chunk addresses below carry the 3-byte offset
-    {
-        const uint8_t *ib = img + b * (int64_t)ICL_IMG_BYTES;
+    constexpr int RW = STEM_PW / 4; // dwords per patch row
+    static_assert(STEM_PW % 4 == 0, "patch rows are whole dwords");
+    constexpr int NDW = STEM_PH * RW + 4;
+    constexpr int NV = (NDW + 255) / 256;
+    uint32_t pv[NV];
+    auto patch_fetch = [&](int tile) {
+        const int tx = tile % 7, ty = (tile / 7) % 14;
+        const uint8_t *ib = img + (int64_t)(tile / 98) * (int64_t)ICL_IMG_BYTES;
         const int iy0 = ty * 16 - 3, bx0 = (tx * 32 - 3) * 3 - 3;
-        constexpr int RW = STEM_PW / 4; // dwords per patch row
-        static_assert(STEM_PW % 4 == 0, "patch rows are whole dwords");
-        uint32_t *p32 = reinterpret_cast<uint32_t *>(patch);
-        constexpr int NDW = STEM_PH * RW + 4;
-        uint32_t v[(NDW + 255) / 256];
 #pragma unroll
-        for (int q = 0; q < (NDW + 255) / 256; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int i = tid + q * 256;
             const int pr = i / RW, pc = i - pr * RW;
             const int iy = iy0 + pr, bx = bx0 + pc * 4;
             const bool ok = i < NDW && pr < STEM_PH && (unsigned)iy < 224u && (unsigned)bx < 672u;
-            v[q] = ok ? *reinterpret_cast<const uint32_t *>(ib + iy * 672 + bx) : 0u;
+            pv[q] = ok ? *reinterpret_cast<const uint32_t *>(ib + iy * 672 + bx) : 0u;
         }
+    };
+    auto patch_store = [&]() {
+        uint32_t *p32 = reinterpret_cast<uint32_t *>(patch);
 #pragma unroll
-        for (int q = 0; q < (NDW + 255) / 256; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int i = tid + q * 256;
-            if (i < NDW) p32[i] = v[q];
+            if (i < NDW) p32[i] = pv[q];
         }
-    }
-    __syncthreads();
+    };
     // chunk roles: lane cuts the chunk (row, logical slot ls) for 4 tile rows; ls is fixed per lane
     const int ls = tid & 7;
     const float sc255 = (float)(1.0 / 255.0);
@@ -427,28 +432,45 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restric
             *reinterpret_cast<uint4 *>(smem + NKS * WST + buf * XST + row * CV_ROWB + (lds_swz(row, ls) << 4)) = *reinterpret_cast<const uint4 *>(v);
         }
     };
-    f32x16 acc[1][2];
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][bb][r] = 0.0f;
-    gather(0, 0);
-    __syncthreads(); // also drains the weight DMA
     const int fr = lane & 31, fh = lane >> 5;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    patch_fetch(tile);
+    patch_store();
+    __syncthreads();
+    for (;;) {
+        const int tx = tile % 7, ty = (tile / 7) % 14;
+        const int64_t b = tile / 98;
+        const int64_t m0 = (b * 112 + ty * 8) * 112 + tx * 16;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles; // workgroup-uniform
+        f32x16 acc[1][2];
 #pragma unroll
-    for (int j = 0; j < NKS; ++j) {
-        if (j + 1 < NKS) gather(j + 1, (j + 1) & 1);
-        conv_mma_kstep<T, BN>(smem + j * WST, smem + NKS * WST + (j & 1) * XST, wm, wn, fr, fh, acc);
-        __syncthreads();
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][bb][r] = 0.0f;
+        gather(0, 0);
+        if (has_next) patch_fetch(next); // in flight while this tile is computed
+        __syncthreads();                 // (the first time: also drains the weight DMA)
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            if (j + 1 < NKS) gather(j + 1, (j + 1) & 1);
+            conv_mma_kstep<T, BN>(smem + j * WST, smem + NKS * WST + (j & 1) * XST, wm, wn, fr, fh, acc);
+            __syncthreads();
+        }
+        if (has_next) patch_store(); // every gather of this tile has read the patch
+        conv_epilogue<T, BN, true>(p, ep_smem, acc, m0, 0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
+        if (!has_next) break;
+        tile = next;
+        __syncthreads(); // the next patch is in LDS, the epilogue tile is free again
     }
-    conv_epilogue<T, BN, true>(p, smem, acc, m0, 0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
 }
 
 template <typename T>
 static constexpr size_t stem_lds_bytes()
 {
-    const size_t st = (size_t)(STEM_K / T::BK) * 64 * CV_ROWB + 2 * (size_t)CV_BM * CV_ROWB + STEM_PH * STEM_PW + 16, ep = (size_t)64 * (64 + 4) * 4;
-    return st > ep ? st : ep;
+    // weights + two activation buffers + the input patch, then (16-byte aligned) the fp32 epilogue tile: the weights stay resident
+    return (((size_t)(STEM_K / T::BK) * 64 * CV_ROWB + 2 * (size_t)CV_BM * CV_ROWB + STEM_PH * STEM_PW + 16 + 15) & ~(size_t)15) + (size_t)64 * (64 + 4) * 4;
 }
 
 // MaxPool 3x3/2 p1 (padding never wins), NHWC, one thread per 16-byte channel chunk of one output pixel.
@@ -1039,7 +1061,9 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
         a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
         a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
         icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
-        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3((unsigned)a.gx), dim3(256), stem_lds_bytes<T>(), strm, d_img, a);
+        const int per_cu = std::max<int>(1, (int)((size_t)160 * 1024 / stem_lds_bytes<T>()));
+        const unsigned stem_grid = (unsigned)std::min<int64_t>(a.gx, (int64_t)per_cu * ctx->prop.multiProcessorCount);
+        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3(stem_grid), dim3(256), stem_lds_bytes<T>(), strm, d_img, a);
     }
     {
         icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
