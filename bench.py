@@ -313,9 +313,12 @@ def main():
                                              "computes the rows of up to 16 independent merges from that one pass (SURVEY.md 8d quotes "
                                              "4*n_live*D per merge: 16x these bytes)",
                          "valu": {"achieved": round(tfl, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_F32_TFLOPS, 4),
+                                  "measured_unfused_ceiling": 61.0, "frac_of_measured_ceiling": round(tfl / 61.0, 4),
                                   "note": "the exact update is 3 UNFUSED fp32 ops per (new row, live cluster, k) -- the reference's rounding "
-                                          "forbids FMA -- so half of the FMA-counted vector peak (78.6 TFLOP/s) is its ceiling; with 16 rows "
-                                          "per pass the kernel is bound by vector-ALU issue, not by HBM"},
+                                          "forbids FMA -- so half of the FMA-counted vector peak (78.6 TFLOP/s) is its nominal ceiling; measured "
+                                          "(scratch/pk_rate_bench.hip) v_pk_add_f32 / v_pk_mul_f32 issue every 5.2-5.7 cycles against 3.2 for "
+                                          "the scalar ops, i.e. unfused packed fp32 tops out at ~61 TFLOP/s on this part (ward_dist_exact_kernel "
+                                          "runs at that rate); with 16 rows per pass the kernel is bound by vector-ALU issue, not by HBM"},
                          "note": "one workgroup per 64 live clusters streams their centroids once (LDS-DMA ring) and runs 16 in-order sums; "
                                  "SURVEY.md 8d classifies the merge loop as HBM-bound, so the HBM fraction is reported as `frac`, the "
                                  "vector-ALU fraction beside it; launches after the last merge of a 64-step chunk are empty",
