@@ -1940,6 +1940,35 @@ __global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d,
 static_assert(WX_SG % 16 == 0 && WX_SG % WX_L == 0 && WX_CPIECES % WX_L == 0 && WX_SG % WB_SG == 0, "a stage is dealt evenly to the loader waves");
 static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
 
+// Wave-wide unsigned minimum without the LDS crossbar: four DPP steps give every lane its row's minimum (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror -- min is idempotent, so mirrored partners do), four v_readlane + three scalar mins join the rows.
+// Every lane must be active.  The result is wave-uniform.  (A 6-step __shfl_down tree costs six dependent ds_bpermute round
+// trips per 32 bits: 2.4 us per block for the update kernel's four 64-bit keys.)
+__device__ __forceinline__ unsigned wave_umin32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); // quad_perm:[1,0,3,2]
+    v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); // quad_perm:[2,3,0,1]
+    v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
+    v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); // row_mirror
+    v = o < v ? o : v;
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+// ... of 64-bit keys (value bits << 32 | column): the smallest high word, then the smallest low word among its holders
+__device__ __forceinline__ unsigned long long wave_umin64(unsigned long long k)
+{
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned m = wave_umin32(hi);
+    const unsigned l = wave_umin32(hi == m ? lo : 0xffffffffu);
+    return ((unsigned long long)m << 32) | l;
+}
+
 // The new centroids of chains 2p and 2p+1, interleaved element by element: cnewI[p][k] = {c_2p[k], c_2p+1[k]}.  A chain wave
 // runs both chains of its pair with PACKED fp32 ops ({x[k], x[k]} - {cA[k], cB[k]}, squared, added to {sA, sB}: 3 v_pk
 // instructions per k for two chains instead of 4 -- the update kernel is VALU-issue bound), which needs cA[k] and cB[k] in
@@ -2491,13 +2520,8 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_down(key, off, 64);
-            key = o < key ? o : key;
-            const unsigned long long o2 = __shfl_down(key2, off, 64);
-            key2 = o2 < key2 ? o2 : key2;
-        }
+        key = wave_umin64(key); // (every lane of a chain wave is active here)
+        key2 = wave_umin64(key2);
         if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
         if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
         WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)

@@ -45,6 +45,20 @@ __global__ void k(float *out, const float *in, int iters)
                 asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(q) : "v"(d));
                 asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i & 3]) : "v"(q));
             }
+        } else if (MODE == 8) { // independent v_pk_fma_f32
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c));
+        } else if (MODE == 9) { // the kernel's pattern written with v_pk_fma_f32 only (x*1 - c, d*d + 0, q*1 + s: the same roundings)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f2 d, q;
+                asm volatile("v_pk_fma_f32 %0, %1, 1.0, %2 op_sel_hi:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a[1 + (i & 3)]), "v"(c));
+                asm volatile("v_pk_fma_f32 %0, %1, %1, 0" : "=v"(q) : "v"(d));
+                asm volatile("v_pk_fma_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,1]" : "+v"(a[0]) : "v"(q));
+            }
+        } else if (MODE == 10) { // scalar v_fma_f32 independent
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i].x) : "v"(c.x));
         } else if (MODE == 7) { // scalar version of the pattern for two chains: 6 scalar ops per k
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -97,5 +111,8 @@ int main()
     run<5>("(pk sub, pk mul, pk add) one running sum", 24, out, in);
     run<6>("(pk sub, pk mul, pk add) four running sums", 24, out, in);
     run<7>("scalar (2 sub, 2 mul, 2 add) one running pair", 48, out, in);
+    run<8>("v_pk_fma_f32, 8 independent", 8, out, in);
+    run<9>("(pk fma x*1-c, pk fma d*d+0, pk fma q*1+s) one running sum", 24, out, in);
+    run<10>("v_fma_f32, 8 independent", 8, out, in);
     return 0;
 }
