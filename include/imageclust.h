@@ -74,7 +74,9 @@ int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes); /* host only, 
 
 /* ---- embed: replaces PreprocessImage + GetImageEmbedding (embeddings.go:46-116,119-163) ----------------- */
 /* n images, each 224*224*3 u8, HWC, RGB (i.e. after the reference's resize + BGR->RGB).  out is n x head fp32.
- * head: ICL_HEAD_POOLED or ICL_HEAD_DENSE0.  prec: ICL_PREC_*.  Batches internally (default 256). */
+ * head: ICL_HEAD_POOLED or ICL_HEAD_DENSE0.  prec: ICL_PREC_*.  Batches internally (default 256).
+ * Host buffers (pageable memory is fine) are streamed through the GPU in slabs of 4096 images; the upload of the next slab
+ * (a helper thread owned by the call) overlaps the forward passes of the current one.  The _dev variant takes device pointers. */
 int icl_embed_u8(icl_ctx *ctx, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
 int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head, int prec, float *d_out);
 /* One image file (baseline or progressive Huffman JPEG, or binary PPM "P6"): decode, bilinear resize to 224x224
