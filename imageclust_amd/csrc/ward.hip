@@ -8,9 +8,24 @@
 // and the merged cluster is appended last, :55-56,:240-241), so its row-major "first strict minimum" scan
 // (:123-131) is the lexicographic minimum of (value, larger id, smaller id).  The MaxFloat32 ban of oversize
 // pairs (:228-234) is a memo of size_p+size_q > maxSize, and sizes of live clusters never change, so it is a
-// static per-pair mask.  Distances live in a packed lower triangle indexed by creation id; each row keeps a
-// cached (min, argmin) that only needs a rescan when its argmin partner dies.  All arithmetic that feeds a
-// comparison is fp32, unfused, in the reference's order (this file is compiled with -ffp-contract=off).
+// static per-pair mask.  A pair lives in the ROW of the cluster with the larger creation id; each row keeps a cached
+// (min, argmin) that only needs a rescan when its argmin partner dies.  All arithmetic that feeds a comparison is
+// fp32, unfused, in the reference's order (this file is compiled with -ffp-contract=off).
+//
+// Storage (round 3): rows and columns of the distance matrix are RECYCLED instead of being indexed by creation id
+// (which needed 2N rows of growing length: 8 N^2 bytes, 500 GB at N = 250 000).  The matrix is (N + WB_K) rows x ld
+// floats (4 N^2 bytes: 40 GB at 100 000, 250 GB at 250 000 -- one 288 GB MI355X):
+//   * COLUMNS are slots [0, N): singleton i sits in column i; a merged cluster inherits the column of its
+//     higher-position parent a when the merge commits (mcol[c] = mcol[a]); msz[col] / mcid[col] give the size (0: dead)
+//     and the creation id of a column's current occupant.  An entry of row r is valid iff its column's occupant is
+//     alive, size-compatible and OLDER than r (mcid[col] < r): cells left behind by earlier occupants fail that test.
+//     Scan order is restored by comparing creation ids: among equal values the smaller mcid wins (the reference's
+//     ascending column order, clustering.go:123-131).
+//   * ROW STORAGE: singleton r owns row r; the cluster created by merge q writes its row into one of WB_K spare rows
+//     (q < WB_K) or into the storage of a_{q-WB_K}, the higher-position member of the merge committed WB_K merges
+//     earlier -- dead by then, and never the storage of a cluster that is still tentative or alive (a batch holds at
+//     most WB_K tentative merges, so a truncated batch leaves every live row intact).  rowoff[creation id] is therefore
+//     written by the finish kernels when a cluster is picked.
 #pragma clang fp contract(off)
 
 #include "icl_common.h"
@@ -31,10 +46,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #else
 #define WB_TIMER(stmt)
 #endif
-#ifndef WB_K
-#define WB_K 16 /* merges attempted per batched step; a power of two <= 16.  With the first-generation update kernel (WB_K / 4 workgroups per slot block) 16 gained nothing over 8; with ward_update_batch2_kernel (one workgroup per block runs all chains from one fetch) N=100k takes 14.9 merges per step and the merge loop 2.27 s -> 1.87 s */
-static_assert((WB_K & (WB_K - 1)) == 0 && WB_K >= 4 && WB_K <= 16, "lane-indexed tables assume a power of two");
-#endif
+#define WB_K 16 /* merges attempted per batched step (a power of two: lane-indexed tables): N=100k takes 15.6 merges per step */
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
 #define WB_RM 4 /* rows each of them takes (matches wg, wg + WB_R, ...): hub clusters leave hundreds of rows dirty */
 #define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 192 are re-minimised per step; the rest stays lazy) */
@@ -62,8 +74,6 @@ struct ward_batch_state {
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
     int32_t blk_next, blk_pad;       // the persistent main workgroups' block counter (zeroed every step by ward_interleave_kernel)
-    unsigned long long refined, pruned_waves, chain_waves, dirty_rows; // pruning statistics: entries made exact on demand; chain waves that stopped early / ran; new rows installed with a bound only
-    unsigned long long prune_hist[4][34]; // -DICL_WARD_TIMERS what-if: [beta index][stage a chain wave could stop at (32 = never), 33 = rows whose minimum exceeds tau]
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
     int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
     int32_t pa_rows[WB_R][WB_PA_CAP];              // rows of the slice whose cached partner is a member of the batch
@@ -100,9 +110,14 @@ struct icl_ward_ws {
     int32_t *asz = nullptr;    // [M] size if alive else 0
     float *rowmin = nullptr;   // [M]
     int32_t *rownn = nullptr;  // [M]
-    int64_t *rowoff = nullptr; // [M+1] float offset of row r in Dtri (rows padded to 4 floats)
-    float *Dtri = nullptr;
+    int64_t *rowoff = nullptr; // [M+1] float offset in Dtri of the row storage of creation id r (singletons: r * ld; merged clusters: set when picked)
+    int32_t *mcol = nullptr;   // [M] column of creation id r (singletons: r; merged clusters: inherited from parent a at commit)
+    int32_t *msz = nullptr;    // [ld] by column: size of the occupant if alive else 0
+    int32_t *mcid = nullptr;   // [ld] by column: creation id of the occupant
+    float *Dtri = nullptr;     // (N + WB_K) rows x ld floats
+    int64_t ld = 0;            // row pitch in floats (N rounded up to 64)
     int64_t dtri_floats = 0;
+    std::vector<std::pair<std::pair<int64_t, int64_t>, float *>> staged; // foreign distance rows [lo, hi) in transport (packed) format, unpacked by the next cluster call
     int32_t *merges = nullptr; // [2*N]
     ward_state *st = nullptr;
     // find_closest scratch
@@ -110,11 +125,11 @@ struct icl_ward_ws {
     int32_t *fc_nn = nullptr;
     int64_t fc_cap = 0;
     int64_t *fc_out = nullptr;
-    std::vector<int64_t> h_rowoff;
     // hipGraph of GRAPH_STEPS merge steps (all step-varying state lives in device memory, so one capture replays)
     hipGraphExec_t graph_exec = nullptr;
     int graph_max_size = -1;
     int graph_lw = -1;
+    bool upd_attr = false, wx_attr = false; // the kernels' > 64 KB dynamic-LDS opt-in has been made on this context's device
 };
 
 void icl_ward_free(icl_ctx *ctx)
@@ -124,8 +139,10 @@ void icl_ward_free(icl_ctx *ctx)
     ctx->ward_rowoff_n = 0;
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
-    void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
-                    w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out};
+    void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out};
+    for (auto &sp : w->staged)
+        if (sp.second) (void)hipFree(sp.second);
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -370,9 +387,59 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
     }
 }
 
-// Initial row caches: one workgroup per row r of the packed triangle (columns 0..r-1).
+// Row scan of the merge loop (recycled storage, see the file header): columns [0, len) of the row of creation id my_id.  A
+// column counts iff its occupant is alive (msz > 0), size-compatible (the static ban mask, clustering.go:228-234), OLDER than
+// the row's cluster (mcid < my_id: everything else in the row is a cell an earlier occupant of the column left behind) and not
+// excluded (ex: creation ids of the tentative batch's members, -1 = unused).  The result is PER THREAD (the caller reduces with
+// block_argmin): smallest value, then smallest creation id -- the reference's first strict minimum in ascending column order
+// (clustering.go:123-131).  bi is a CREATION ID (-1: none).  Rows start 16-byte aligned; msz / mcid hold ld >= len entries.
+__device__ __forceinline__ int64_t ward_row_len(int64_t r, int64_t n) { return r < n ? r : n; } // singleton r: partners are the singletons below it; merged clusters: any column
+__device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                           int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi)
+{
+    bv = ICL_MAXF;
+    bi = -1;
+    int e8[2 * WB_K];
+#pragma unroll
+    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
+    auto visit = [&](float v, int m, int c) {
+        if (m > 0 && m + my_size <= max_size && c < my_id && (v < bv || (v == bv && c < bi))) {
+            bool ex_hit = false;
+#pragma unroll
+            for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == c;
+            if (!ex_hit) {
+                bv = v;
+                bi = c;
+            }
+        }
+    };
+    const int64_t nvec = len >> 2;
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        float4 v[4];
+        int4 m[4], c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const bool has = q < nvec;
+            v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            m[j] = has ? reinterpret_cast<const int4 *>(msz)[q] : make_int4(0, 0, 0, 0);
+            c[j] = has ? reinterpret_cast<const int4 *>(mcid)[q] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            visit(v[j].x, m[j].x, c[j].x);
+            visit(v[j].y, m[j].y, c[j].y);
+            visit(v[j].z, m[j].z, c[j].z);
+            visit(v[j].w, m[j].w, c[j].w);
+        }
+    }
+    for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) visit(row[q], msz[q], mcid[q]);
+}
+
+// Initial row caches: one workgroup per singleton row r (columns 0..r-1).
 __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
-                                                             const int32_t *__restrict__ asz, int max_size, int64_t nrows,
+                                                             const int32_t *__restrict__ asz, const int32_t *__restrict__ msz,
+                                                             const int32_t *__restrict__ mcid, int max_size, int64_t nrows,
                                                              float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
     __shared__ float sv[16];
@@ -385,7 +452,8 @@ __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__res
             bv = ICL_MAXF;
             bi = -1;
         } else {
-            scan_row(Dtri + rowoff[r], r, asz, my, max_size, bv, bi);
+            const int noex[1] = {-1};
+            scan_row_m(Dtri + rowoff[r], r, msz, mcid, (int)r, my, max_size, noex, 0, bv, bi);
         }
         block_argmin(bv, bi, sv, si);
         if (threadIdx.x == 0) {
@@ -438,8 +506,9 @@ __global__ __launch_bounds__(1024) void select_dense_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------------------
 // Merge loop kernels
 // ------------------------------------------------------------------------------------------------------------
-__global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_id, int32_t *id_slot, int32_t *asz,
-                                 float *rowmin, int32_t *rownn, ward_state *st, int32_t target)
+__global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, int32_t *slot_id, int32_t *id_slot, int32_t *asz,
+                                 float *rowmin, int32_t *rownn, int64_t *rowoff, int32_t *mcol, int32_t *msz, int32_t *mcid,
+                                 ward_state *st, int32_t target)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < S) slot_id[i] = i < n ? (int32_t)i : -1;
@@ -448,6 +517,12 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         asz[i] = i < n ? 1 : 0;
         rowmin[i] = ICL_MAXF;
         rownn[i] = -1;
+        mcol[i] = i < n ? (int32_t)i : -1;        // a merged cluster inherits its parent's column when its merge commits
+        rowoff[i] = i < n + WB_K ? i * ld : 0;    // singletons and the WB_K spare rows; later clusters: set when they are picked
+    }
+    if (i < ld) {
+        msz[i] = i < n ? 1 : 0;
+        mcid[i] = i < n ? (int32_t)i : 0x7fffffff;
     }
     if (i == 0) {
         st->done = 0;
@@ -473,8 +548,6 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int32_t *slot_
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
-        for (int j = 0; j < 4 * 34; ++j) (&st->B.prune_hist[0][0])[j] = 0;
-        st->B.refined = st->B.pruned_waves = st->B.chain_waves = st->B.dirty_rows = 0;
         st->B.blk_next = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
     }
@@ -531,7 +604,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // (clustering.go:119-133), ties included.
 __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
                                                int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
-                                               const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st,
+                                               const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
+                                               const int32_t *__restrict__ mcid, int max_size, ward_state *__restrict__ st,
                                                float *sv, int *si, int *sh)
 {
     if (st->done) return;
@@ -576,7 +650,10 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
         if (!dirty) break;
         float rv;
         int ri;
-        scan_row(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, rv, ri);
+        {
+            const int noex[1] = {-1};
+            scan_row_m(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri);
+        }
         block_argmin(rv, ri, sv, si);
         if (threadIdx.x == 0) {
             rowmin[bi] = rv;
@@ -594,13 +671,14 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
 // preselect(0): before the first merge there is no update to run beside.
 __global__ __launch_bounds__(1024) void ward_presel_kernel(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
                                                           int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
-                                                          const int64_t *__restrict__ rowoff, int max_size,
+                                                          const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
+                                                          const int32_t *__restrict__ mcid, int max_size,
                                                           ward_state *__restrict__ st)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int sh[2];
-    ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+    ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
 }
 
 // finish(t), ONE workgroup: (a) publish the row cache of the cluster created by merge t-1 (its minimum was reduced by
@@ -613,7 +691,8 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
                                                           int32_t *__restrict__ slot_id, int32_t *__restrict__ id_slot,
                                                           int32_t *__restrict__ asz, float *__restrict__ rowmin,
                                                           int32_t *__restrict__ rownn, int32_t *__restrict__ merges,
-                                                          ward_state *__restrict__ st)
+                                                          int64_t *__restrict__ rowoff, int32_t *__restrict__ mcol, int32_t *__restrict__ msz,
+                                                          int32_t *__restrict__ mcid, int64_t ld, ward_state *__restrict__ st)
 {
     __shared__ int sh[7];
     if (st->done) return;
@@ -692,6 +771,16 @@ __global__ __launch_bounds__(1024) void ward_finish_kernel(int64_t n, int d, int
         asz[a] = 0;
         asz[b] = 0;
         asz[c] = sa + sb;
+        {
+            // recycled storage (file header): c takes a's column; its row goes to a spare row or to the storage of the
+            // higher-position member of the merge WB_K merges back (dead, and used by nobody else)
+            const int ca = mcol[a], cb = mcol[b];
+            mcol[c] = ca;
+            msz[ca] = sa + sb;
+            mcid[ca] = c;
+            msz[cb] = 0;
+            rowoff[c] = t < WB_K ? (n + t) * ld : rowoff[merges[3 * (t - WB_K)]];
+        }
         rowmin[a] = ICL_MAXF;
         rowmin[b] = ICL_MAXF;
         rowmin[c] = ICL_MAXF;
@@ -735,8 +824,9 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
                                                                float *__restrict__ Crow, const float *__restrict__ cnew,
                                                                const int32_t *__restrict__ slot_id,
                                                                const int32_t *__restrict__ asz, const int32_t *__restrict__ rownn,
-                                                               const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
-                                                               ward_state *__restrict__ st,
+                                                               const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
+                                                               const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                                               float *__restrict__ Dtri, ward_state *__restrict__ st,
                                                                int max_size, int64_t n, float *__restrict__ rowmin,
                                                                int32_t *__restrict__ rownn_w)
 {
@@ -746,7 +836,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
         float *sv = reinterpret_cast<float *>(upd_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
         int *sh = si + 16;
-        ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, max_size, st, sv, si, sh);
+        ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -793,6 +883,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
     const int x = slot < nlive ? xraw : -1;
     bool live = x >= 0 && x != c;
     const int sx = live ? asz[x] : 0;
+    const int mx = live ? mcol[x] : 0; // the column of this lane's cluster
     live = live && sx > 0;
     const int sc = sa + sb; // == asz[c]
     const bool act = live && (sx + sc <= max_size); // else: banned for good (static mask); value never read
@@ -868,7 +959,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
     const float val = (num / den) * s;
     unsigned long long key = ~0ull;
     if (act) {
-        Dtri[rowoff[c] + x] = val;
+        Dtri[rowoff[c] + mx] = val;
         // values are >= +0 (a sum of squares scaled by a positive ratio): their bit patterns order like the floats,
         // so min over (bits<<32 | x) is "smallest value, then smallest column" == the row scan's first strict minimum
         if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
@@ -886,13 +977,15 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
 // 12 bytes of reads per live cluster instead of 4*D.  Algebraically equal to clustering.go:84's centroid recompute
 // but NOT bit-equal (and it starts from the MFMA distance tile): cluster ids are reported, not asserted, against the
 // reference.  Same riders as the exact kernel: preselect(t+1) and the (unused here) compaction workgroup.
-__device__ __forceinline__ float tri_at(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int p, int q)
+__device__ __forceinline__ float tri_at(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol, int p, int q)
 {
-    return p > q ? Dtri[rowoff[p] + q] : Dtri[rowoff[q] + p];
+    return p > q ? Dtri[rowoff[p] + mcol[q]] : Dtri[rowoff[q] + mcol[p]]; // the pair lives in the row of the larger creation id, at the other's column
 }
 
 __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
-                                                                    const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                                    const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
+                                                                    const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                                                    float *__restrict__ Dtri,
                                                                     ward_state *__restrict__ st, int max_size, int64_t n,
                                                                     float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
@@ -901,7 +994,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
     __shared__ int sh[2];
     __shared__ unsigned long long skey[UPD_THREADS / 64];
     if (blockIdx.x == gridDim.x - 1) {
-        ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
         return;
     }
     if (st->done || !st->cur_valid) return;
@@ -916,10 +1009,10 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
     const bool act = live && (sx + sa + sb <= max_size);
     unsigned long long key = ~0ull;
     if (act) {
-        const float dax = tri_at(Dtri, rowoff, a, x), dbx = tri_at(Dtri, rowoff, b, x), dab = tri_at(Dtri, rowoff, a, b);
+        const float dax = tri_at(Dtri, rowoff, mcol, a, x), dbx = tri_at(Dtri, rowoff, mcol, b, x), dab = tri_at(Dtri, rowoff, mcol, a, b);
         float v = ((float)(sa + sx) * dax + (float)(sb + sx) * dbx - (float)sx * dab) / (float)(sa + sb + sx);
         v = v > 0.0f ? v : 0.0f; // keeps the (bits, column) key order == value order
-        Dtri[rowoff[c] + x] = v;
+        Dtri[rowoff[c] + mcol[x]] = v;
         if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
     }
 #pragma unroll
@@ -952,21 +1045,8 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
 // simply stay in the caches.  Row c_j is computed against the clusters alive at ITS time: members of p_0..p_j are
 // excluded, c_0..c_{j-1} are included (as "virtual slots" whose columns are the new centroids).
 // ============================================================================================================
-#ifndef WB_P
-#define WB_P 4                        /* producer waves: with 16 k-groups per stage the workgroup needs 64 KB of LDS and 128 VGPRs, so two fit a CU */
-#endif
-#ifndef WB_PRING
-#define WB_PRING 0                    /* 1: producers square the differences (ring of p per chain): measured SLOWER (update 50 us vs 37 us per launch, the ds_write_b128 path saturates); 0: chain waves do (ring of x) */
-#endif
-#if WB_PRING
-#define WB_GP 2
-#else
-#define WB_GP 4
-#endif
-#define WB_SG (WB_P * WB_GP)          /* k-groups per stage */
-#define WB_KC 4                        /* chain waves per workgroup: one per SIMD */
-#define WB_NH (WB_K / WB_KC)            /* workgroups sharing a 64-slot block, each with WB_KC of the batch's chains */
-#define WB_THREADS (64 * (WB_P + WB_KC)) /* WB_KC chain waves (one per tentative cluster) + WB_P producers */
+#define WB_SG 16                      /* k-groups a centroid image is padded to a multiple of; the finish kernels re-make the first 2 * WB_SG groups of a committed CT4 column themselves */
+#define WB_THREADS 512                /* workgroup size of the Lance-Williams batch kernel (one lane per live cluster) */
 #define WB_PAD_G (4 * WB_SG)
 static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 1) / WB_SG * WB_SG; }
 
@@ -987,227 +1067,6 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
         k = o < k ? o : k;
     }
     return k;
-}
-
-// ---- partial-sum pruning (round 2) --------------------------------------------------------------------------------
-// The batched update kernel may stop a chain early: the in-order fp32 sum of squares only grows (every term is >= +0 and
-// rounded addition is monotone), so (size factor) x (partial sum) is a LOWER BOUND of the pair's final Ward value, bit-exactly,
-// without any error analysis.  Such an entry is stored NEGATED: v < 0 means "the true value is >= -v".  Every reader of a row
-// goes through scan_row_ex, which REFINES on demand: a flagged entry whose bound does not exceed the best exact value is
-// recomputed from the two committed centroids in the reference's order (clustering.go:136-157) and written back exact.
-struct wrefine {
-    const float *Crow;       // [slot][d] committed centroids
-    const int32_t *id_slot;  // creation id -> slot
-    int d;
-    int self_id;             // the row's own cluster
-    unsigned long long *stat; // refined entries (statistics), may be null
-};
-#define WB_REF_CAP 1024
-
-__device__ __forceinline__ float ward_exact_pair(const wrefine &rf, const int32_t *__restrict__ asz, int x)
-{
-    const float *a = rf.Crow + (int64_t)rf.id_slot[x] * rf.d, *b = rf.Crow + (int64_t)rf.id_slot[rf.self_id] * rf.d;
-    float s = 0.0f;
-    if ((rf.d & 3) == 0) {
-        for (int k = 0; k < rf.d; k += 4) {
-            const float4 av = *reinterpret_cast<const float4 *>(a + k), bv = *reinterpret_cast<const float4 *>(b + k);
-            float df = av.x - bv.x; // clustering.go:139
-            float p = df * df;      // :154 product
-            s = s + p;              // :154 sum, strictly in k order
-            df = av.y - bv.y;
-            p = df * df;
-            s = s + p;
-            df = av.z - bv.z;
-            p = df * df;
-            s = s + p;
-            df = av.w - bv.w;
-            p = df * df;
-            s = s + p;
-        }
-    } else {
-        for (int k = 0; k < rf.d; ++k) {
-            const float df = a[k] - b[k];
-            const float p = df * df;
-            s = s + p;
-        }
-    }
-    const int sx = asz[x], sc = asz[rf.self_id];
-    const float num = (float)((int64_t)sx * (int64_t)sc); // :142
-    const float den = (float)(sx + sc);                    // :143
-    return (num / den) * s;                                // :144
-}
-
-// scan_row with up to 2*WB_K excluded columns (the tentative batch's members).  Returns the row's first minimum over the live,
-// size-compatible, non-excluded columns.  With rf == nullptr the row must hold exact values only and the result is PER THREAD
-// (the caller reduces); with rf the result is already reduced over the workgroup (sv / si: scratch of 16 floats / ints) and
-// flagged entries are refined as needed.
-__device__ __noinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
-                                             int max_size, const int *ex, int nex, float &bv, int &bi, const wrefine *rf, float *sv, int *si)
-{
-    __shared__ int ref_cnt;
-    __shared__ int ref_col[WB_REF_CAP];
-    int e8[2 * WB_K];
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
-    const int64_t nvec = len >> 2; // packed rows start 16-byte aligned
-    // one pass over the row.  collect: append the flagged candidates whose bound is <= bound to ref_col; fv = smallest bound
-    // among the flagged candidates that were NOT appended
-    auto pass = [&](bool collect, float bound, float &tv, int &ti, float &fv) {
-        tv = ICL_MAXF;
-        ti = -1;
-        fv = ICL_MAXF;
-        auto visit = [&](float v, int m, int col) {
-            if (!(m > 0 && m + my_size <= max_size)) return;
-            if (v < 0.0f) { // flagged lower bound
-                bool ex_hit = false;
-#pragma unroll
-                for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
-                if (ex_hit) return;
-                const float lb = -v;
-                if (collect && lb <= bound) {
-                    const int at = atomicAdd(&ref_cnt, 1);
-                    if (at < WB_REF_CAP) {
-                        ref_col[at] = col;
-                        return;
-                    }
-                }
-                fv = lb < fv ? lb : fv;
-                return;
-            }
-            if (v < tv) {
-                bool ex_hit = false;
-#pragma unroll
-                for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
-                if (!ex_hit) {
-                    tv = v;
-                    ti = col;
-                }
-            }
-        };
-        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
-            float4 v[4];
-            int4 m[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * blockDim.x;
-                const bool has = q < nvec;
-                v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
-                m[j] = has ? reinterpret_cast<const int4 *>(asz)[q] : make_int4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t q = q0 + (int64_t)j * blockDim.x;
-                const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-                const int mm[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) visit(vv[e], mm[e], (int)(q * 4 + e));
-            }
-        }
-        for (int64_t c = nvec * 4 + threadIdx.x; c < len; c += blockDim.x) visit(row[c], asz[c], (int)c);
-    };
-    float fv;
-    pass(false, 0.0f, bv, bi, fv);
-    if (!rf) return; // exact rows only (FAST mode, first-generation kernels): the caller reduces
-    block_argmin(bv, bi, sv, si);
-    {
-        int dummy = 0;
-        block_argmin(fv, dummy, sv, si);
-    }
-    while (fv < ICL_MAXF && fv <= bv) { // a flagged entry could win or tie: make those exact (fv == MaxFloat32: no flagged entry is left)
-        if (threadIdx.x == 0) ref_cnt = 0;
-        __syncthreads();
-        float tv, f2v;
-        int ti;
-        pass(true, bv, tv, ti, f2v);
-        __syncthreads();
-        const int m = ref_cnt < WB_REF_CAP ? ref_cnt : WB_REF_CAP;
-        float rv = ICL_MAXF;
-        int ri = -1;
-        if ((int)threadIdx.x < m) {
-            const int col = ref_col[threadIdx.x];
-            const float val = ward_exact_pair(*rf, asz, col);
-            row[col] = val; // exact from now on
-            if (val < ICL_MAXF) {
-                rv = val;
-                ri = col;
-            }
-        }
-        for (int q = (int)threadIdx.x + (int)blockDim.x; q < m; q += blockDim.x) { // workgroups smaller than the cap
-            const int col = ref_col[q];
-            const float val = ward_exact_pair(*rf, asz, col);
-            row[col] = val;
-            argmin_combine(rv, ri, val < ICL_MAXF ? val : ICL_MAXF, val < ICL_MAXF ? col : -1);
-        }
-        if (rf->stat && threadIdx.x == 0) atomicAdd(rf->stat, (unsigned long long)m);
-        block_argmin(rv, ri, sv, si);
-        argmin_combine(bv, bi, rv, ri);
-        int dummy = 0;
-        block_argmin(f2v, dummy, sv, si);
-        fv = f2v;
-        __syncthreads();
-    }
-}
-
-// The plain scan (exact rows only; the result is PER THREAD, the caller reduces): the hot path of the spare / preselection
-// workgroups.  The refining variant above is kept out of line so that its registers do not burden the update kernel.
-__device__ __forceinline__ void scan_row_plain(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
-                                               int max_size, const int *ex, int nex, float &bv, int &bi)
-{
-    bv = ICL_MAXF;
-    bi = -1;
-    int e8[2 * WB_K];
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
-    const int64_t nvec = len >> 2; // packed rows start 16-byte aligned
-    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
-        float4 v[4];
-        int4 m[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t q = q0 + (int64_t)j * blockDim.x;
-            const bool has = q < nvec;
-            v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
-            m[j] = has ? reinterpret_cast<const int4 *>(asz)[q] : make_int4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t q = q0 + (int64_t)j * blockDim.x;
-            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            const int mm[4] = {m[j].x, m[j].y, m[j].z, m[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (mm[e] > 0 && mm[e] + my_size <= max_size && vv[e] < bv) {
-                    const int col = (int)(q * 4 + e);
-                    bool ex_hit = false;
-#pragma unroll
-                    for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == col;
-                    if (!ex_hit) {
-                        bv = vv[e];
-                        bi = col;
-                    }
-                }
-            }
-        }
-    }
-    for (int64_t c = nvec * 4 + threadIdx.x; c < len; c += blockDim.x) {
-        const float v = row[c];
-        const int m = asz[c];
-        bool ok = m > 0 && m + my_size <= max_size && v < bv;
-#pragma unroll
-        for (int z = 0; z < 2 * WB_K; ++z) ok &= e8[z] != (int)c;
-        if (ok) {
-            bv = v;
-            bi = (int)c;
-        }
-    }
-}
-
-__device__ __forceinline__ void scan_row_ex(float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz, int my_size,
-                                            int max_size, const int *ex, int nex, float &bv, int &bi, const wrefine *rf = nullptr,
-                                            float *sv = nullptr, int *si = nullptr)
-{
-    if (rf) scan_row_refine(row, len, asz, my_size, max_size, ex, nex, bv, bi, rf, sv, si);
-    else scan_row_plain(row, len, asz, my_size, max_size, ex, nex, bv, bi);
 }
 
 // Pops the WB_WTOP smallest keys of a wave (every lane offers k1 < k2, its two smallest; a key with bit 0 set is a SENTINEL:
@@ -1246,7 +1105,8 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
 // The finish kernel installs them if the whole batch commits; the preselection waits for the ones it needs.
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
-                                 int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine *rf0 = nullptr)
+                                 const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                 int max_size, ward_state *__restrict__ st, float *sv, int *si)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ int lcnt;
@@ -1350,12 +1210,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         float rv = ICL_MAXF;
         int ri = -1;
         if (r >= 0) {
-            wrefine rf;
-            if (rf0) {
-                rf = *rf0;
-                rf.self_id = r;
-            }
-            scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, 2 * WB_K, rv, ri, rf0 ? &rf : nullptr, sv, si);
+            scan_row_m(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri);
             block_argmin(rv, ri, sv, si);
         }
         if (threadIdx.x == 0) {
@@ -1371,8 +1226,9 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
 }
 
 __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
-                                     float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, int max_size,
-                                     ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine *rf0 = nullptr)
+                                     float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
+                                     const int32_t *__restrict__ mcid, int max_size,
+                                     ward_state *__restrict__ st, float *sv, int *si, int *sh)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
@@ -1565,12 +1421,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        wrefine rf;
-        if (rf0) {
-            rf = *rf0;
-            rf.self_id = r;
-        }
-        scan_row_ex(Dtri + rowoff[r], r, asz, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, rf0 ? &rf : nullptr, sv, si);
+        scan_row_m(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri);
         block_argmin(rv, ri, sv, si); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
@@ -1606,339 +1457,34 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     }
 }
 
-// update for a batch: rows of up to WB_K tentative clusters in one pass over the centroids.
-__global__ __launch_bounds__(WB_THREADS, 4) void ward_update_batch_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
-                                                                      const float *__restrict__ Crow, const float *__restrict__ cnewK,
-                                                                      int64_t cn_stride,
-                                                                      const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
-                                                                      const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
-                                                                      ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring (x: [2][WB_SG][64], p: [2][WB_KC][WB_SG][64]), then [WB_KC][dqp+pad] centroids
-#if WB_PRING
-    float4 (*ring)[WB_KC][WB_SG][64] = reinterpret_cast<float4 (*)[WB_KC][WB_SG][64]>(wb_lds);
-    constexpr int RING_F4 = 2 * WB_KC * WB_SG * 64;
-#else
-    float4 (*ring)[WB_SG][64] = reinterpret_cast<float4 (*)[WB_SG][64]>(wb_lds);
-    constexpr int RING_F4 = 2 * WB_SG * 64;
-#endif
-    // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
-    if (blockIdx.x < WB_R) {
-        float *sv = reinterpret_cast<float *>(wb_lds);
-        int *si = reinterpret_cast<int *>(sv + 16);
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
-        return;
-    }
-    if (blockIdx.x == WB_R) {
-        float *sv = reinterpret_cast<float *>(wb_lds);
-        int *si = reinterpret_cast<int *>(sv + 16);
-        int *sh = si + 16;
-        WB_TIMER(const unsigned long long t0 = wall_clock64();)
-        WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
-        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
-    // blocks WB_R+1 .. WB_R+WB_NH: "virtual slots" (lane i = tentative cluster c_i, column = its new centroid)
-    const bool virt = blockIdx.x <= WB_R + WB_NH;
-    const int64_t mb = (int64_t)blockIdx.x - (WB_R + 1 + WB_NH);
-    // workgroups are dealt to the 8 XCDs round-robin in dispatch order: the WB_NH workgroups of a slot block sit exactly
-    // 8 apart (groups of 8 blocks, then their partners), so they share an L2 and run at the same time -- the second
-    // reader of a centroid column hits the L2 instead of fetching it again (at large N the centroid store is far bigger
-    // than the Infinity Cache and the kernel is bound by that traffic)
-    const int64_t mblk = virt ? 0 : (mb / (8 * WB_NH)) * 8 + (mb & 7);
-    const int half = virt ? (int)blockIdx.x - (WB_R + 1) : (int)((mb >> 3) % WB_NH); // which WB_KC chains this workgroup runs
-    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
-    const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
-    int pa[WB_K], pb[WB_K], psc[WB_K];
-#pragma unroll
-    for (int j = 0; j < WB_K; ++j) {
-        pa[j] = st->B.a[j];
-        pb[j] = st->B.b[j];
-        psc[j] = st->B.sa[j] + st->B.sb[j];
-    }
-    if (!virt && mblk * 64 >= S) return; // grid padding (the block count is rounded up to a multiple of 8): nothing to read
-    const int64_t slot = virt ? lane : mblk * 64 + lane;
-    const int xraw = virt ? -1 : slot_id[slot];
-    const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
-    const unsigned voff = virt ? (unsigned)((lane < WB_K ? lane : 0) * cn_stride * 4) : (unsigned)slot * 16u;
-    const int64_t row_bytes = virt ? 16 : S * 16;
-    const int pj = wave - WB_KC; // producer index (waves WB_KC..), chain index = half*WB_KC + wave (waves 0..WB_KC-1)
-    const bool producer = wave >= WB_KC;
-    struct xq { float4 g0, g1, g2, g3; }; // WB_GP (2 or 4) k-groups of one slot, kept in named registers
-    static_assert(WB_GP == 4 || WB_GP == 2, "xq holds two or four groups");
-    // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
-    // streams its centroid from the row-major copy instead and re-makes the column on the way
-    bool dirty_lane = false;
-    const int dq_real = d >> 2;
-    auto load = [&](int stage) {
-        const int g0 = stage * WB_SG + pj * WB_GP;
-        const char *rb = ctb + (int64_t)g0 * row_bytes + voff;
-        const char *r0 = rb, *r1 = rb + row_bytes, *r2 = rb + 2 * row_bytes, *r3 = rb + 3 * row_bytes;
-        if (dirty_lane) {
-            const char *cr = reinterpret_cast<const char *>(Crow) + ((int64_t)slot * d + (int64_t)g0 * 4) * 4;
-            if (g0 + 0 < dq_real) r0 = cr;
-            if (g0 + 1 < dq_real) r1 = cr + 16;
-            if (WB_GP == 4 && g0 + 2 < dq_real) r2 = cr + 32;
-            if (WB_GP == 4 && g0 + 3 < dq_real) r3 = cr + 48;
-        }
-        xq v;
-        v.g0 = *reinterpret_cast<const float4 *>(r0);
-        v.g1 = *reinterpret_cast<const float4 *>(r1);
-        if (WB_GP == 4) {
-            v.g2 = *reinterpret_cast<const float4 *>(r2);
-            v.g3 = *reinterpret_cast<const float4 *>(r3);
-        } else {
-            v.g2 = v.g3 = make_float4(0, 0, 0, 0);
-        }
-        return v;
-    };
-    xq va = {}, vb = {}, vc = {};
-    if (producer) {
-        va = load(0);
-        vb = load(1);
-    }
-    if (done || nb <= half * WB_KC) return;
-    if (!virt && mblk * 64 >= nlive) return;
-    // which rows does this lane's cluster take part in?
-    int x, sx;
-    if (virt) {
-        x = lane < nb ? (int)(n + t + lane) : -1;
-        sx = 0;
-#pragma unroll
-        for (int j = 0; j < WB_K; ++j)
-            if (lane == j) sx = psc[j];
-    } else {
-        x = slot < nlive ? xraw : -1;
-        sx = x >= 0 ? asz[x] : 0;
-    }
-    unsigned okmask = 0;
-    bool survives = false;
-    {
-        bool alive = x >= 0 && sx > 0;
-#pragma unroll
-        for (int j = 0; j < WB_K; ++j) {
-            if (j < nb) {
-                if (virt) {
-                    if (alive && lane < j && sx + psc[j] <= max_size) okmask |= 1u << j;
-                } else {
-                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
-                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
-                }
-            }
-        }
-        survives = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
-    }
-    okmask >>= half * WB_KC; // this workgroup's chains
-    const int nd = virt ? 0 : dirty_n0;
-    for (int z = 0; z < nd; ++z) dirty_lane |= __shfl(dirty_s0, z, 64) == (int)slot;
-    if (!__any((okmask & ((1u << WB_KC) - 1u)) != 0)) {
-        // nothing to compute here, but a stale column must not outlive this step's dirty list
-        if (half == 0) {
-            unsigned long long dm = __ballot(dirty_lane);
-            while (dm) {
-                const int l = __ffsll((long long)dm) - 1;
-                dm &= dm - 1;
-                const int64_t sl = mblk * 64 + l;
-                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WB_THREADS)
-                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
-            }
-        }
-        return;
-    }
-    float4 *cn4 = wb_lds + RING_F4;
-    const int cnl = dqp; // float4s per centroid image in LDS (only stages < dqp / WB_SG are ever read)
-    const int nch = nb - half * WB_KC < WB_KC ? nb - half * WB_KC : WB_KC; // chains run here
-    for (int j = 0; j < nch; ++j)
-        for (int g = threadIdx.x; g < cnl; g += WB_THREADS)
-            cn4[j * cnl + g] = reinterpret_cast<const float4 *>(cnewK + (half * WB_KC + j) * cn_stride)[g];
-    __syncthreads();
-    float s = 0.0f;
-    auto patch_ct = [&](const xq &v, int stage) { // re-make a dirty column (both workgroups of a slot block write the same values)
-        if (dirty_lane && stage >= 2) {
-            const int g0 = stage * WB_SG + pj * WB_GP;
-            if (g0 + 0 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 0, S, slot)) = v.g0;
-            if (g0 + 1 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 1, S, slot)) = v.g1;
-            if (WB_GP == 4 && g0 + 2 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 2, S, slot)) = v.g2;
-            if (WB_GP == 4 && g0 + 3 < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g0 + 3, S, slot)) = v.g3;
-        }
-    };
-    const bool chain = wave < nch;
-#if WB_PRING
-    // producers stream x once and square its differences to this workgroup's WB_KC new centroids: a chain wave then
-    // only reads p and adds (5 instructions per 4 k instead of 10 -- the chain wave's instruction stream is the
-    // critical path); the price is WB_KC ds_write_b128 per column group, the expensive LDS operation
-    auto sq = [&](const float4 &xv, const float4 &cv) {
-        const f2 xa = {xv.x, xv.y}, xb = {xv.z, xv.w};
-        const f2 ca = {cv.x, cv.y}, cb = {cv.z, cv.w};
-        const f2 da = xa - ca, db = xb - cb; // clustering.go:139 via :84
-        const f2 qa = da * da, qb = db * db; // :154 products, each rounded
-        return make_float4(qa.x, qa.y, qb.x, qb.y);
-    };
-    auto produce = [&](const xq &v, int buf, int stage) {
-        const int g0 = stage * WB_SG + pj * WB_GP;
-#pragma unroll
-        for (int j = 0; j < WB_KC; ++j) {
-            if (j < nch) {
-                ring[buf][j][pj * WB_GP + 0][lane] = sq(v.g0, cn4[j * cnl + g0 + 0]);
-                ring[buf][j][pj * WB_GP + 1][lane] = sq(v.g1, cn4[j * cnl + g0 + 1]);
-            }
-        }
-        patch_ct(v, stage);
-    };
-    auto consume = [&](int buf, int stage) {
-        (void)stage;
-        float4 pv[WB_SG];
-#pragma unroll
-        for (int g = 0; g < WB_SG; ++g) pv[g] = ring[buf][wave][g][lane];
-#pragma unroll
-        for (int g = 0; g < WB_SG; ++g) {
-            s = s + pv[g].x; // :154 the running sum, strictly in k order
-            s = s + pv[g].y;
-            s = s + pv[g].z;
-            s = s + pv[g].w;
-        }
-    };
-#else
-    // producers only move x (global -> LDS); every chain wave squares its own differences
-    auto produce = [&](const xq &v, int buf, int stage) {
-        ring[buf][pj * WB_GP + 0][lane] = v.g0;
-        ring[buf][pj * WB_GP + 1][lane] = v.g1;
-        ring[buf][pj * WB_GP + 2][lane] = v.g2;
-        ring[buf][pj * WB_GP + 3][lane] = v.g3;
-        patch_ct(v, stage);
-    };
-    const float4 *cnj = cn4 + (chain ? wave : 0) * cnl;
-    auto consume = [&](int buf, int stage) {
-        const float4 *cs = cnj + stage * WB_SG;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 xv[WB_SG / 2], cv[WB_SG / 2];
-#pragma unroll
-            for (int g = 0; g < WB_SG / 2; ++g) {
-                xv[g] = ring[buf][h * (WB_SG / 2) + g][lane];
-                cv[g] = cs[h * (WB_SG / 2) + g];
-            }
-#pragma unroll
-            for (int g = 0; g < WB_SG / 2; ++g) {
-                const f2 xa = {xv[g].x, xv[g].y}, xb = {xv[g].z, xv[g].w};
-                const f2 ca = {cv[g].x, cv[g].y}, cb = {cv[g].z, cv[g].w};
-                const f2 da = xa - ca, db = xb - cb; // clustering.go:139 via :84
-                const f2 qa = da * da, qb = db * db; // :154 products, each rounded
-                s = s + qa.x;                        // :154 the running sum, strictly in k order
-                s = s + qa.y;
-                s = s + qb.x;
-                s = s + qb.y;
-            }
-        }
-    };
-#endif
-    const int nstage = dqp / WB_SG;
-    for (int i = 0; i < nstage; i += 3) {
-        if (producer) {
-            vc = load(i + 2);
-            produce(va, i & 1, i);
-        }
-        __syncthreads();
-        if (chain) consume(i & 1, i);
-        if (i + 1 < nstage) {
-            if (producer) {
-                va = load(i + 3);
-                produce(vb, (i + 1) & 1, i + 1);
-            }
-            __syncthreads();
-            if (chain) consume((i + 1) & 1, i + 1);
-        }
-        if (i + 2 < nstage) {
-            if (producer) {
-                vb = load(i + 4);
-                produce(vc, i & 1, i + 2);
-            }
-            __syncthreads();
-            if (chain) consume(i & 1, i + 2);
-        }
-    }
-    if (!chain) return;
-    {
-        const int j = half * WB_KC + wave;
-        unsigned long long key = ~0ull;
-        if ((okmask >> wave) & 1u) {
-            int sc = psc[0];
-#pragma unroll
-            for (int q = 1; q < WB_K; ++q)
-                if (j == q) sc = psc[q];
-            const float num = (float)((int64_t)sx * (int64_t)sc);
-            const float den = (float)(sx + sc);
-            const float val = (num / den) * s;
-            const int64_t c = n + t + j;
-            Dtri[rowoff[c] + x] = val;
-            if (val < ICL_MAXF) key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
-        }
-        // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the validation
-        // needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's cache after a full
-        // commit (otherwise the row would be born dirty whenever its partner is merged by a later pick)
-        unsigned long long key2 = survives ? key : ~0ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_down(key, off, 64);
-            key = o < key ? o : key;
-            const unsigned long long o2 = __shfl_down(key2, off, 64);
-            key2 = o2 < key2 ? o2 : key2;
-        }
-        if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
-        if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
-        WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
-        WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// Batched exact update, second generation ("one fetch per block").  ward_update_batch_kernel above splits the batch's
-// chains over WB_NH workgroups per 64-slot block, so every centroid column is fetched WB_NH times by the CUs (once from
-// HBM, then from the XCD's L2): at N = 100 000 the launch is bound by that per-CU fetch path (37 us per block pair and
-// round), not by HBM, and WB_K = 16 (four workgroups per block) gains nothing.  Here ONE workgroup per block runs ALL
-// chains from one pass over its 64 columns:
+// Batched exact update ("one fetch per block").  ONE persistent workgroup per CU runs ALL chains of the batch from one pass
+// over the 64 centroid columns of each block it draws (the first generation split a block's chains over WB_K/4 workgroups, so
+// every column was fetched that many times by the CUs -- once from HBM, then from the XCD's L2 -- and the launch was bound by
+// that per-CU fetch path: 37 us per block pair and round at N = 100 000):
 //   * WX_L loader waves move the columns global -> LDS with LDS-DMA (no VGPR staging, no ds_write), WX_R stages of
-//     16 k-groups (16 KB) in a ring, WX_R-1 of them in flight (80 KB per CU at WX_R = 6), counted vmcnt + one raw
-//     barrier per stage;
-//   * WX_CW chain waves (two per SIMD), each running WX_CPW = WB_K / WX_CW in-order sums interleaved (the dependent
-//     add latency of one hides behind the other).  The new centroids ride the same ring (one more 1 KB piece per loader
-//     wave and stage: 16 chains x 16 k-groups x 16 B) and are read with broadcast ds_read_b128: all of a chain wave's
+//     WX_SG k-groups in a ring, WX_R-1 of them in flight, counted vmcnt + one raw barrier per stage;
+//   * WX_CW chain waves (two per SIMD), each running two in-order sums in the halves of packed fp32 ops.  The new centroids
+//     ride the same ring (pair-interleaved copy, cnewI) and are read with broadcast ds_read_b128: all of a chain wave's
 //     operands are LDS reads, which return in order, so hipcc pipelines them with counted lgkmcnt waits.  (Measured and
 //     dropped: the centroids as scalar loads into SGPR operands -- SMEM returns out of order, every wait becomes
-//     lgkmcnt(0) and the s_load latency is exposed four times per stage: 57 us per block instead of 36.)
-// Arithmetic, row order, masks, keys and the dirty-column protocol are those of ward_update_batch_kernel.
+//     lgkmcnt(0) and the s_load latency is exposed four times per stage: 57 us per block instead of 36; two sets of 64 slots
+//     per workgroup sharing the centroid reads: +6 % at N=100k, -30 % at N=10k; partial-sum pruning with on-demand refinement:
+//     exact, but isolated rows cost more to refine than the update saves -- DESIGN.md 3.)
 // ------------------------------------------------------------------------------------------------------------
-#ifndef WX_PRUNE
-#define WX_PRUNE 0                     /* 1: build the partial-sum pruning experiment (ICL_WARD_PRUNE=<beta> then enables it at run time); 0: compiled out -- its refinement code costs the update kernel ~180 spilled VGPRs in the preselection role */
-#endif
-#ifndef WX_R
 #define WX_R 3                         /* ring stages (40 KB each with 32 k-groups per stage: 32 KB of columns + 8 KB of centroids); depth 4..7 at 16 groups per stage measured within 2 % of each other */
-#endif
-#ifndef WX_L
-#define WX_L 4                         /* loader waves (4 or 2) */
-#endif
-#define WX_CW 8                        /* chain waves */
-#define WX_CPW ((WB_K + WX_CW - 1) / WX_CW) /* chains per chain wave */
+#define WX_L 4                         /* loader waves */
+#define WX_CW 8                        /* chain waves, two tentative merges each */
 #define WX_THREADS (64 * (WX_L + WX_CW))
-#ifndef WX_SG
 #define WX_SG 32                       /* k-groups per ring stage (one raw barrier per stage: 32 halves the barriers of a block against 16) */
-#endif
+#define WX_NCH 16                      /* chains the centroid pieces always cover (cnew is allocated for 16) */
 #define WX_XOPS (WX_SG / WX_L)         /* column pieces per loader wave and stage */
 #define WX_CPIECES (WX_NCH * WX_SG / 64) /* centroid pieces per stage: 16 chains x WX_SG k-groups x 16 B in 1 KB pieces */
 #define WX_COPS (WX_CPIECES / WX_L)    /* ... per loader wave */
 #define WX_OPS (WX_XOPS + WX_COPS)
-#define WX_NCH 16                      /* chains the centroid pieces always cover (cnew is allocated for 16) */
-#ifndef WX_NS
-#define WX_NS 1                        /* sets of 64 slots per workgroup (they share the centroid reads and the per-workgroup overhead).  Measured: 2 sets = 89 us per 128 slots against 47.7 us per 64 -- the chain waves are VALU-issue bound (8 instructions per chain and k-group at 4 cycles each: 27 us floor per 64 slots and 16 chains), so sharing LDS reads buys 6 % at N=100k and costs 30 % at N=10k (half as many workgroups) */
-#endif
-#define WX_STAGE_F4 (WX_NS * WX_SG * 64 + WX_NCH * WX_SG) /* float4 per ring stage: WX_NS sets of columns, then [chain][k-group] centroids */
+#define WX_STAGE_F4 (WX_SG * 64 + WX_NCH * WX_SG) /* float4 per ring stage: 64 columns, then [pair][k-group][2] centroids */
 static_assert(WX_SG % 16 == 0 && WX_SG % WX_L == 0 && WX_CPIECES % WX_L == 0 && WX_SG % WB_SG == 0, "a stage is dealt evenly to the loader waves");
-static_assert(WX_CPW == 1 || WX_CPW == 2, "one or two chains per chain wave");
+static_assert(WB_K == 2 * WX_CW, "two chains per chain wave");
 
 // Wave-wide unsigned minimum without the LDS crossbar: four DPP steps give every lane its row's minimum (quad_perm xor 1, xor 2,
 // row_half_mirror, row_mirror -- min is idempotent, so mirrored partners do), four v_readlane + three scalar mins join the rows.
@@ -2112,25 +1658,23 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
     static_assert(WB_K <= 16, "two chunks of 8 commits / picks");
 }
 
-#ifndef WX_WGS_PER_CU
-#define WX_WGS_PER_CU 1                /* main workgroups resident per CU (2 needs <= 80 VGPRs and <= 76 KB of LDS each: WX_SG=16, WX_R=3) */
-#endif
-__global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
+__global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       const float *__restrict__ cnewI, int64_t cn_stride,
                                                                       const int32_t *__restrict__ slot_id, const int32_t *__restrict__ id_slot,
                                                                       const int32_t *__restrict__ asz,
-                                                                      const int64_t *__restrict__ rowoff, float *__restrict__ Dtri,
+                                                                      const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
+                                                                      const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                                                      float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, int diag, float prune_beta)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
     extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
-    // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then 64 slots each
+    // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
-        const wrefine rf0{Crow, id_slot, d, -1, &st->B.refined};
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, (WX_PRUNE && prune_beta > 0.0f) ? &rf0 : nullptr);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si);
         return;
     }
     if (blockIdx.x == WB_R) {
@@ -2139,8 +1683,7 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         int *sh = si + 16;
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        const wrefine rf0{Crow, id_slot, d, -1, &st->B.refined};
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh, (WX_PRUNE && prune_beta > 0.0f) ? &rf0 : nullptr);
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -2163,18 +1706,16 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     }
     __syncthreads();
     // PERSISTENT main workgroups: the grid holds at most one per CU; each draws 64-slot blocks from a device-wide counter
-    // (reset every step by ward_interleave_kernel) until the live range is exhausted.  The per-launch state above is read
-    // once per workgroup instead of once per block, there is no workgroup launch per block, and workgroups that start late
-    // (their CU ran a spare / preselection workgroup first) simply draw fewer blocks.
-    __shared__ int wexit_stage[WX_CW];
+    // (reset every step by ward_finish_data_kernel / ward_interleave_kernel) until the live range is exhausted.  The per-launch
+    // state above is read once per workgroup instead of once per block, there is no workgroup launch per block, and workgroups
+    // that start late (their CU ran a spare / preselection workgroup first) simply draw fewer blocks.
     // The NEXT block is drawn and its per-slot state fetched while the current one is being computed: chain wave 0 (whose vmcnt
     // is otherwise unused) issues the counter atomic, the slot_id load, the dependent asz load and the LDS hand-over at four
     // points of the stage loop, so each wait finds its data already there.  Drawn on the spot, the same chain cost every block
     // ~5 us (two workgroup barriers around a device atomic) + ~4 us of dependent loads: a quarter of the block's 46 us.
-    static_assert(WX_NS == 1, "the next-block hand-over holds one set of 64 slots");
-    __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_dirty[2][64];
+    __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_mx[2][64], nx_dirty[2][64];
     const int nmain = (int)gridDim.x - (WB_R + 2); // persistent main workgroups
-    int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_dirty = 0; // chain wave 0 only
+    int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_mx = 0, pf_dirty = 0; // chain wave 0 only
     auto pf_advance = [&](const int upto, const int par) {
         if (pf_done < 1 && upto >= 1) { // draw (blocks 0 .. nmain-1 are the workgroups' first blocks: the counter hands out the rest)
             pf_raw = lane == 0 ? nmain + atomicAdd(&st->B.blk_next, 1) : 0;
@@ -2192,15 +1733,17 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             pf_xr = on ? slot_id[sl] : -1; // last: a loop after the load would wait for it at once
             pf_done = 2;
         }
-        if (pf_done < 3 && upto >= 3) { // their sizes
+        if (pf_done < 3 && upto >= 3) { // their sizes and their columns in the distance matrix
             pf_x = ((int64_t)pf_blk * 64 + lane < nlive) ? pf_xr : -1;
             pf_sx = pf_x >= 0 ? asz[pf_x] : 0;
+            pf_mx = pf_x >= 0 ? mcol[pf_x] : 0;
             pf_done = 3;
         }
         if (pf_done < 4 && upto >= 4) { // hand over
             if (lane == 0) nx_blk[par] = pf_blk;
             nx_x[par][lane] = pf_x;
             nx_sx[par][lane] = pf_sx;
+            nx_mx[par][lane] = pf_mx;
             nx_dirty[par][lane] = pf_dirty;
             pf_done = 4;
         }
@@ -2220,44 +1763,28 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
     const int64_t mblk = virt ? (blk_it == 0 ? 0 : -1) : __builtin_amdgcn_readfirstlane(nx_blk[par]); // (an LDS read: tell hipcc it is wave-uniform)
     rp = __builtin_amdgcn_readfirstlane(rp);
     pf_done = 0;
-    // A workgroup owns WX_NS sets of 64 consecutive slots (the virtual-slot workgroup: one set).  The sets share every
-    // centroid read and the per-launch overhead; a set beyond the live range is simply inactive.
-    if (mblk < 0 || (!virt && mblk * (64 * WX_NS) >= nlive)) break;
-    int64_t slot[WX_NS];
-    int x[WX_NS], sx[WX_NS];
-    unsigned okmask[WX_NS];
-    bool survives[WX_NS], dirty_lane[WX_NS], set_on[WX_NS];
+    if (mblk < 0 || (!virt && mblk * 64 >= nlive)) break;
     const int dq_real = d >> 2;
-    bool any_ok = false, any_dirty = false;
-    // ---- part 1: what the loaders need (slot, live sets, dirty columns) -- then the ring's first stages are requested BEFORE
-    // the dependent slot_id -> asz loads of part 2, which resolve while the DMA is in flight
-#pragma unroll
-    for (int u = 0; u < WX_NS; ++u) {
-        slot[u] = virt ? lane : (mblk * WX_NS + u) * 64 + lane;
-        set_on[u] = virt ? u == 0 : (mblk * WX_NS + u) * 64 < nlive; // wave-uniform
-        // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
-        // streams its centroid from the row-major copy instead and the column is re-made on the way
-        dirty_lane[u] = !virt && set_on[u] && nx_dirty[par][lane] != 0;
-        any_dirty |= __any(dirty_lane[u]);
-    }
+    // ---- part 1: what the loaders need (slot, dirty columns) -- then the ring's first stages are requested BEFORE the
+    // dependent slot_id -> asz loads of part 2, which resolve while the DMA is in flight
+    const int64_t slot = virt ? lane : mblk * 64 + lane;
+    // a "dirty" lane's CT4 column is stale beyond the first two stages (the finish kernel only re-made those): it
+    // streams its centroid from the row-major copy instead and the column is re-made on the way
+    const bool dirty_lane = !virt && nx_dirty[par][lane] != 0;
+    const bool any_dirty = __any(dirty_lane);
     const int nstage = (dqp + WX_SG - 1) / WX_SG; // the CT4 columns and the centroid images are zero-padded past dqp: (0-0)^2 adds +0
     const bool loader = wave >= WX_CW;
     const int pj = wave - WX_CW; // loader index
     const char *ctb = virt ? reinterpret_cast<const char *>(cnewK) : reinterpret_cast<const char *>(CT);
     const int64_t row_bytes = virt ? 16 : S * 16;
     const unsigned ring_base = lds_addr_of(wb_lds);
-    // centroid pieces.  WX_CPW == 2: the ring holds [pair][k-group][2] float4 = {cA[4g+2h], cB[4g+2h], cA[4g+2h+1], cB[4g+2h+1]} from the
-    // interleaved copy: lane l of piece q fetches pair 2q + l/32, k-group (l%32)/2, half l%2.  WX_CPW == 1: [chain][k-group] from cnewK.
-    // piece q of a stage covers ring float4 indices [64q, 64q+64) of the centroid area; index = unit * WX_SG*(WX_CPW==2 ? 2 : 1) + within,
-    // unit = pair (WX_CPW == 2: within = 2*g + h) or chain (within = g)
+    // centroid pieces: the ring holds [pair][k-group][2] float4 = {cA[4g+2h], cB[4g+2h], cA[4g+2h+1], cB[4g+2h+1]} from the
+    // interleaved copy: lane l of piece q fetches pair 2q + l/32, k-group (l%32)/2, half l%2 (piece q covers ring float4 indices
+    // [64q, 64q+64) of the centroid area; index = pair * 2*WX_SG + 2*g + h)
     auto csrc_of = [&](int q, int stage) -> const char * {
         const int idx = q * 64 + lane;
-        if (WX_CPW == 2) {
-            const int pair = idx / (2 * WX_SG), w = idx % (2 * WX_SG), g = w >> 1, h = w & 1;
-            return reinterpret_cast<const char *>(cnewI) + ((int64_t)pair * 2 * cn_stride + ((int64_t)stage * WX_SG + g) * 8 + h * 4) * 4;
-        }
-        const int ch = idx / WX_SG, g = idx % WX_SG;
-        return reinterpret_cast<const char *>(cnewK) + ((int64_t)ch * cn_stride + ((int64_t)stage * WX_SG + g) * 4) * 4;
+        const int pair = idx / (2 * WX_SG), w = idx % (2 * WX_SG), g = w >> 1, h = w & 1;
+        return reinterpret_cast<const char *>(cnewI) + ((int64_t)pair * 2 * cn_stride + ((int64_t)stage * WX_SG + g) * 8 + h * 4) * 4;
     };
     auto issue = [&](int stage, int phase, int64_t slot_l, bool dirty_l) { // this loader wave's pieces of one stage (of this block, or of the next one: phase = its ring slot of stage 0): 64 lanes x 16 B each, lane-linear in the ring
         const int g0 = stage * WX_SG + pj * WX_XOPS;
@@ -2274,167 +1801,104 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
         }
 #pragma unroll
         for (int q = 0; q < WX_COPS; ++q)
-            glds16_asm(csrc_of(pj * WX_COPS + q, stage), sbase + (unsigned)(WX_NS * WX_SG * 1024 + (pj * WX_COPS + q) * 1024));
+            glds16_asm(csrc_of(pj * WX_COPS + q, stage), sbase + (unsigned)(WX_SG * 1024 + (pj * WX_COPS + q) * 1024));
     };
-    const bool two = WX_NS > 1 && set_on[WX_NS - 1]; // wave-uniform: both sets live (the usual case away from the tail)
-    const bool do_load = !(diag & 2), do_chain = !(diag & 1); // timing diagnostics only (ICL_WX_DIAG): results are wrong when set
     // cross-block ring: with enough stages per block the loaders request the NEXT block's first WX_R-1 stages while this block's
     // last ones are computed (its index and dirty columns are handed over by then), so a block does not start on an empty ring
-    const bool xblk = !virt && !(WX_PRUNE && prune_beta >= 1.0f) && nstage >= 8 && do_load;
+    const bool xblk = !virt && nstage >= 8;
     const int iD = xblk ? (3 * nstage) / 4 - 1 : nstage - 1; // the stage after whose barrier chain wave 0 hands the next block over
-    if (loader && do_load && !pre)
-        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i, rp, slot[0], dirty_lane[0]);
+    if (loader && !pre)
+        for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i, rp, slot, dirty_lane);
     // ---- part 2: which rows does this lane's cluster take part in?
-#pragma unroll
-    for (int u = 0; u < WX_NS; ++u) {
-        if (virt) {
-            x[u] = (u == 0 && lane < nb) ? (int)(n + t + lane) : -1;
-            sx[u] = lane < WB_K ? psc[lane] : 0;
-        } else {
-            x[u] = nx_x[par][lane];
-            sx[u] = nx_sx[par][lane];
-        }
-        okmask[u] = 0;
-        bool alive = x[u] >= 0 && sx[u] > 0;
+    int x, sx, mx; // this lane's cluster: creation id, size, column in the distance matrix
+    if (virt) {
+        x = lane < nb ? (int)(n + t + lane) : -1;
+        sx = lane < WB_K ? psc[lane] : 0;
+        mx = lane < nb ? mcol[pa[lane]] : 0; // c_i takes over a_i's column when it commits: the rows c_j, j > i, hold no entry for the (then dead) a_i
+    } else {
+        x = nx_x[par][lane];
+        sx = nx_sx[par][lane];
+        mx = nx_mx[par][lane];
+    }
+    unsigned okmask = 0;
+    bool survives;
+    {
+        bool alive = x >= 0 && sx > 0;
 #pragma unroll
         for (int j = 0; j < WB_K; ++j) {
             if (j < nb) {
                 if (virt) {
-                    if (alive && lane < j && sx[u] + psc[j] <= max_size) okmask[u] |= 1u << j;
+                    if (alive && lane < j && sx + psc[j] <= max_size) okmask |= 1u << j;
                 } else {
-                    alive = alive && x[u] != pa[j] && x[u] != pb[j]; // members of p_0..p_j are gone when c_j is created
-                    if (alive && sx[u] + psc[j] <= max_size) okmask[u] |= 1u << j;
+                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
                 }
             }
         }
-        survives[u] = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
-        any_ok |= __any(okmask[u] != 0);
+        survives = alive; // not a member of ANY pick of the batch (virtual slots are the new clusters themselves)
     }
-    if (!any_ok) {
+    if (!__any(okmask != 0)) {
         // nothing to compute here (the requested stages must land before the ring is reused), but a stale column must not
         // outlive this step's dirty list
         if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (wave == 0 && !virt) pf_advance(4, par ^ 1);
         rp = (rp + (WX_R - 1 < nstage ? WX_R - 1 : nstage)) % WX_R; // the stages requested for this block were never consumed: the next block's ring starts behind them
         pre = false;
-#pragma unroll
-        for (int u = 0; u < WX_NS; ++u) {
-            unsigned long long dm = __ballot(dirty_lane[u]);
-            while (dm) {
-                const int l = __ffsll((long long)dm) - 1;
-                dm &= dm - 1;
-                const int64_t sl = (mblk * WX_NS + u) * 64 + l;
-                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
-                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
-            }
+        unsigned long long dm = __ballot(dirty_lane);
+        while (dm) {
+            const int l = __ffsll((long long)dm) - 1;
+            dm &= dm - 1;
+            const int64_t sl = mblk * 64 + l;
+            for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
+                *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
         }
         continue;
     }
-    const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * WX_CPW : 0);
-    const int jB = __builtin_amdgcn_readfirstlane(jA + (WX_CPW - 1));
+    const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * 2 : 0); // this chain wave's pair of tentative merges: jA, jA + 1
     const bool chain = wave < WX_CW && jA < nb;
-    float sA[WX_NS], sB[WX_NS];
-#pragma unroll
-    for (int u = 0; u < WX_NS; ++u) sA[u] = sB[u] = 0.0f;
-    f2 sP[WX_NS]; // WX_CPW == 2: {sA, sB} of each slot set as one packed register pair
-#pragma unroll
-    for (int u = 0; u < WX_NS; ++u) sP[u] = f2{0.0f, 0.0f};
-    // one quarter stage (4 k-groups) of NSETS sets x WX_CPW chains: every centroid float4 is read once and used NSETS times.
+    f2 sP = f2{0.0f, 0.0f}; // {sA, sB}: the pair's running sums as one packed register pair
+    // one quarter stage (4 k-groups) of the wave's two chains.
     // (Measured and dropped: an explicit two-register-set software pipeline across quarters -- reads of quarter q+1 issued before
     // quarter q is computed -- is SLOWER than hipcc's own interleaving of the same reads: 54 vs 45 us per block.)
-    auto quarter = [&](const float4 *xr, const float4 *ca, const float4 *cb, auto nsets_tag) {
-        constexpr int NSETS = decltype(nsets_tag)::value;
-        float4 xv[NSETS][4], c0[4], c1[4];
+    auto quarter = [&](const float4 *xr, const float4 *ca) {
+        float4 xv[4], c0[4], c1[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int u = 0; u < NSETS; ++u) xv[u][g] = xr[(u * WX_SG + g) * 64];
-            if (WX_CPW == 2) {
-                c0[g] = ca[2 * g];     // {cA[4g], cB[4g], cA[4g+1], cB[4g+1]}
-                c1[g] = ca[2 * g + 1]; // {cA[4g+2], cB[4g+2], cA[4g+3], cB[4g+3]}
-            } else {
-                c0[g] = ca[g];
-            }
+            xv[g] = xr[g * 64];
+            c0[g] = ca[2 * g];     // {cA[4g], cB[4g], cA[4g+1], cB[4g+1]}
+            c1[g] = ca[2 * g + 1]; // {cA[4g+2], cB[4g+2], cA[4g+3], cB[4g+3]}
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (WX_CPW == 2) {
-                // both chains of the pair in the two halves of packed fp32 ops: {x[k], x[k]} - {cA[k], cB[k]} (clustering.go:139 via
-                // :84), squared (:154 product), added to {sA, sB} (:154 sum) -- each half is rounded exactly like the scalar op, and
-                // each running sum still takes its terms strictly in k order
-                const f2 k0 = {c0[g].x, c0[g].y}, k1 = {c0[g].z, c0[g].w}, k2 = {c1[g].x, c1[g].y}, k3 = {c1[g].z, c1[g].w};
-#pragma unroll
-                for (int u = 0; u < NSETS; ++u) {
-                    const f2 x0 = {xv[u][g].x, xv[u][g].x}, x1 = {xv[u][g].y, xv[u][g].y}, x2 = {xv[u][g].z, xv[u][g].z}, x3 = {xv[u][g].w, xv[u][g].w};
-                    const f2 d0 = x0 - k0, d1 = x1 - k1, d2 = x2 - k2, d3 = x3 - k3;
-                    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
-                    sP[u] = sP[u] + q0;
-                    sP[u] = sP[u] + q1;
-                    sP[u] = sP[u] + q2;
-                    sP[u] = sP[u] + q3;
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NSETS; ++u) {
-                    const f2 xa = {xv[u][g].x, xv[u][g].y}, xb = {xv[u][g].z, xv[u][g].w};
-                    const f2 a0 = {c0[g].x, c0[g].y}, a1 = {c0[g].z, c0[g].w};
-                    const f2 da = xa - a0, db = xb - a1; // clustering.go:139 via :84
-                    const f2 qa = da * da, qb = db * db; // :154 products, each rounded
-                    sA[u] = sA[u] + qa.x;                // :154 the running sum, strictly in k order
-                    sA[u] = sA[u] + qa.y;
-                    sA[u] = sA[u] + qb.x;
-                    sA[u] = sA[u] + qb.y;
-                }
-            }
+            // both chains of the pair in the two halves of packed fp32 ops: {x[k], x[k]} - {cA[k], cB[k]} (clustering.go:139 via
+            // :84), squared (:154 product), added to {sA, sB} (:154 sum) -- each half is rounded exactly like the scalar op, and
+            // each running sum still takes its terms strictly in k order
+            const f2 k0 = {c0[g].x, c0[g].y}, k1 = {c0[g].z, c0[g].w}, k2 = {c1[g].x, c1[g].y}, k3 = {c1[g].z, c1[g].w};
+            const f2 x0 = {xv[g].x, xv[g].x}, x1 = {xv[g].y, xv[g].y}, x2 = {xv[g].z, xv[g].z}, x3 = {xv[g].w, xv[g].w};
+            const f2 d0 = x0 - k0, d1 = x1 - k1, d2 = x2 - k2, d3 = x3 - k3;
+            const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+            sP = sP + q0;
+            sP = sP + q1;
+            sP = sP + q2;
+            sP = sP + q3;
         }
     };
     auto consume = [&](int stage) {
         const float4 *sb_ = wb_lds + ((rp + stage) % WX_R) * WX_STAGE_F4;
         const float4 *xr = sb_ + lane;
-        // wave-uniform addresses: broadcast reads.  WX_CPW == 2: this wave's pair, [k-group][2 halves]; else [chain][k-group]
-        const float4 *ca = sb_ + WX_NS * WX_SG * 64 + (WX_CPW == 2 ? (jA >> 1) * (2 * WX_SG) : jA * WX_SG);
-        const float4 *cb = ca;
+        const float4 *ca = sb_ + WX_SG * 64 + (jA >> 1) * (2 * WX_SG); // wave-uniform address (broadcast reads): this wave's pair, [k-group][2 halves]
 #pragma unroll
-        for (int q = 0; q < WX_SG / 4; ++q) {
-            const float4 *cq = ca + q * 4 * (WX_CPW == 2 ? 2 : 1);
-            if (two) quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, WX_NS>());
-            else quarter(xr + q * 4 * 64, cq, cb, std::integral_constant<int, 1>());
-        }
+        for (int q = 0; q < WX_SG / 4; ++q) quarter(xr + q * 4 * 64, ca + q * 8);
     };
-    // ---- partial-sum pruning: tau = beta x (largest pick value of the batch).  A chain wave stops once EVERY lane's partial value
-    // (size factor x in-order partial sum: a lower bound of the final value, sums of non-negative terms only grow) exceeds tau
-    // for both of its chains; its entries are then stored negated ("true value >= this").  tau >= every pick value of the
-    // batch, so a pruned entry can neither precede a pick (the finish kernel's validation) nor be a row minimum that matters
-    // before it is refined (scan_row_ex).  The virtual-slot workgroup never prunes.
-    const bool prune = WX_PRUNE && prune_beta >= 1.0f && !virt && WX_NS == 1;
-    float tau = ICL_MAXF;
-    float facA = 0.0f, facB = 0.0f; // this lane's size factors for the wave's chains (0: not a valid pair -> never blocks a stop)
-    if (prune) {
-        float vlast = 0.0f;
-#pragma unroll
-        for (int j = 0; j < WB_K; ++j)
-            if (j < nb) vlast = fmaxf(vlast, st->B.val[j]);
-        tau = prune_beta * vlast;
-        if (chain) {
-            const int sa_ = psc[jA], sb_ = psc[jB < WB_K ? jB : 0];
-            if ((okmask[0] >> jA) & 1u) facA = (float)((int64_t)sx[0] * sa_) / (float)(sx[0] + sa_);
-            if (WX_CPW == 2 && jB < nb && ((okmask[0] >> jB) & 1u)) facB = (float)((int64_t)sx[0] * sb_) / (float)(sx[0] + sb_);
-        }
-    }
-    if (threadIdx.x < WX_CW) wexit_stage[threadIdx.x] = (prune && threadIdx.x * WX_CPW < nb) ? (1 << 30) : ((prune ? -1 : (1 << 30))); // idle chain waves count as stopped
-    bool wstopped = false;
     int nxt_blk = -1;
     bool nxt_on = false, nxt_dirty = false; // the next block, once handed over (cross-block ring)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // wexit_stage is set
     for (int i = 0; i < nstage; ++i) {
         if (loader) {
             // stage i has landed once at most the WX_R-2 younger stages are outstanding (in the tail nothing new is issued:
-            // wait for everything, those stages have been in flight all along).  A workgroup with one live set issues fewer
-            // pieces per stage, so its count is smaller.
-            if (i + WX_R - 2 < nstage || nxt_on) { // (nxt_on: the younger stages in flight are the next block's)
-                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_NS * WX_XOPS + WX_COPS)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * (WX_XOPS + WX_COPS)) : "memory");
-            } else
+            // wait for everything, those stages have been in flight all along)
+            if (i + WX_R - 2 < nstage || nxt_on) // (nxt_on: the younger stages in flight are the next block's)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * WX_OPS) : "memory");
+            else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of stage i-1 have returned before its ring slot is refilled
@@ -2446,78 +1910,46 @@ __global__ __launch_bounds__(WX_THREADS, 3 * WX_WGS_PER_CU) void ward_update_bat
             nxt_on = (int64_t)nxt_blk * 64 < nlive;
             nxt_dirty = nxt_on && nx_dirty[par ^ 1][lane] != 0;
         }
-        if (prune && i > 0) { // every chain wave stopped during stage <= i-1: nothing left to compute, stop loading too
-            int stopped = 0;
-#pragma unroll
-            for (int q = 0; q < WX_CW; ++q) stopped += wexit_stage[q] <= i - 1;
-            if (stopped == WX_CW && !any_dirty) break; // (dirty columns must still be re-made from every stage)
-        }
         if (loader) {
             if (any_dirty && i * WX_SG >= 2 * WB_SG) { // re-make the dirty columns (beyond the groups the finish kernel re-made) from the stage that has just landed (rare)
+                const float4 *xr = wb_lds + ((rp + i) % WX_R) * WX_STAGE_F4 + lane;
 #pragma unroll
-                for (int u = 0; u < WX_NS; ++u) {
-                    const float4 *xr = wb_lds + ((rp + i) % WX_R) * WX_STAGE_F4 + u * WX_SG * 64 + lane;
-#pragma unroll
-                    for (int q = 0; q < WX_XOPS; ++q) {
-                        const int g = i * WX_SG + pj * WX_XOPS + q;
-                        if (dirty_lane[u] && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot[u])) = xr[(pj * WX_XOPS + q) * 64];
-                    }
+                for (int q = 0; q < WX_XOPS; ++q) {
+                    const int g = i * WX_SG + pj * WX_XOPS + q;
+                    if (dirty_lane && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot)) = xr[(pj * WX_XOPS + q) * 64];
                 }
             }
-            if (i + WX_R - 1 < nstage) {
-                if (do_load) issue(i + WX_R - 1, rp, slot[0], dirty_lane[0]); // into the slot stage i-1 was read from: every chain wave is past this barrier
-            } else if (nxt_on) // the ring runs on into the next block (its stage 0 sits in slot rp + nstage)
+            if (i + WX_R - 1 < nstage)
+                issue(i + WX_R - 1, rp, slot, dirty_lane); // into the slot stage i-1 was read from: every chain wave is past this barrier
+            else if (nxt_on) // the ring runs on into the next block (its stage 0 sits in slot rp + nstage)
                 issue(i + WX_R - 1 - nstage, rp + nstage, (int64_t)nxt_blk * 64 + lane, nxt_dirty);
-        } else if (chain && do_chain && !wstopped) {
+        } else if (chain) {
             consume(i);
-            if (prune) {
-                const float pa_ = WX_CPW == 2 ? sP[0].x : sA[0], pb_ = WX_CPW == 2 ? sP[0].y : 0.0f;
-                const bool okA = facA == 0.0f || facA * pa_ > tau, okB = facB == 0.0f || facB * pb_ > tau;
-                if (i + 1 < nstage && __all(okA && okB)) {
-                    wstopped = true;
-                    if (lane == 0) wexit_stage[wave] = i;
-                }
-            }
         }
     }
-    if (loader && !nxt_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an early stop leaves ring stages in flight: they must land before the ring is reused / the LDS released (with nxt_on what is in flight belongs to the next block, which waits for it stage by stage)
-    if (wave == 0 && !virt) pf_advance(4, par ^ 1); // few stages (small D) or an early stop: finish the hand-over now
+    if (wave == 0 && !virt) pf_advance(4, par ^ 1); // few stages (small D): finish the hand-over now
     rp = (rp + nstage) % WX_R;
     pre = nxt_on;
     if (!chain) continue;
-    if (prune && lane == 0) {
-        atomicAdd(&st->B.chain_waves, 1ull);
-        if (wstopped) atomicAdd(&st->B.pruned_waves, 1ull);
-    }
 #pragma unroll
-    for (int cc = 0; cc < WX_CPW; ++cc) {
+    for (int cc = 0; cc < 2; ++cc) {
         const int j = jA + cc;
         if (j >= nb) break;
         const int sc = psc[j];
         const int64_t ro = ro_l[j];
-        const int mark = pa[j]; // a_j: dead once c_j exists
         unsigned long long key = ~0ull, key2 = ~0ull;
-#pragma unroll
-        for (int u = 0; u < WX_NS; ++u) {
-            const float s = WX_CPW == 2 ? (cc ? sP[u].y : sP[u].x) : sA[u];
-            if ((okmask[u] >> j) & 1u) {
-                const float num = (float)((int64_t)sx[u] * (int64_t)sc);
-                const float den = (float)(sx[u] + sc);
-                const float val = (num / den) * s;
-                // a stopped wave holds partial sums: val is a lower bound (> tau), stored negated.  Its key is the next float
-                // BELOW the bound with the (dead) member a_j as the column: a row whose smallest key is such a bound is installed
-                // dirty (partner dead) and refined when it reaches the top; "strictly below" makes an exact value that equals a
-                // bound lose to it, so ties are always resolved on exact values.
-                Dtri[ro + x[u]] = wstopped ? -val : val;
-                if (val < ICL_MAXF) {
-                    const unsigned long long k = wstopped ? (((unsigned long long)(__float_as_uint(val) - 1u) << 32) | (unsigned long long)(unsigned)mark)
-                                                          : (((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x[u]);
-                    key = k < key ? k : key;
-                    // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the
-                    // validation needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's
-                    // cache after a full commit
-                    if (survives[u]) key2 = k < key2 ? k : key2;
-                }
+        const float s = cc ? sP.y : sP.x;
+        if ((okmask >> j) & 1u) {
+            const float num = (float)((int64_t)sx * (int64_t)sc);
+            const float den = (float)(sx + sc);
+            const float val = (num / den) * s;
+            Dtri[ro + mx] = val;
+            if (val < ICL_MAXF) {
+                key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+                // ckey: the row's true minimum (members of LATER picks are still alive at c_j's time) -- what the
+                // validation needs; ckey2: the minimum over the clusters that survive the whole batch -- the row's
+                // cache after a full commit
+                if (survives) key2 = key;
             }
         }
         key = wave_umin64(key); // (every lane of a chain wave is active here)
@@ -2544,6 +1976,8 @@ __device__ __forceinline__ float ward_lw_value(float dax, float dbx, float dab, 
 
 __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_t S, const int32_t *__restrict__ slot_id,
                                                                          const int32_t *__restrict__ asz, const int64_t *__restrict__ rowoff,
+                                                                         const int32_t *__restrict__ mcol, const int32_t *__restrict__ msz,
+                                                                         const int32_t *__restrict__ mcid,
                                                                          float *__restrict__ Dtri, ward_state *__restrict__ st, int max_size, int64_t n,
                                                                          float *__restrict__ rowmin, int32_t *__restrict__ rownn)
 {
@@ -2551,11 +1985,11 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
     __shared__ int si[16];
     __shared__ int sh[8];
     if (blockIdx.x < WB_R) {
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si);
         return;
     }
     if (blockIdx.x == WB_R) {
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, max_size, st, sv, si, sh);
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -2606,11 +2040,11 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
                 const int sci = sai + sbi, scj = psa[j] + psb[j];
                 if (sci + scj <= max_size) {
                     // D(c_i, a_j) and D(c_i, b_j) from stored entries, then D(c_j, c_i)
-                    const float d_ci_aj = ward_lw_value(tri_at(Dtri, rowoff, ai, pa[j]), tri_at(Dtri, rowoff, bi, pa[j]), vi_val, sai, sbi, psa[j]);
-                    const float d_ci_bj = ward_lw_value(tri_at(Dtri, rowoff, ai, pb[j]), tri_at(Dtri, rowoff, bi, pb[j]), vi_val, sai, sbi, psb[j]);
+                    const float d_ci_aj = ward_lw_value(tri_at(Dtri, rowoff, mcol, ai, pa[j]), tri_at(Dtri, rowoff, mcol, bi, pa[j]), vi_val, sai, sbi, psa[j]);
+                    const float d_ci_bj = ward_lw_value(tri_at(Dtri, rowoff, mcol, ai, pb[j]), tri_at(Dtri, rowoff, mcol, bi, pb[j]), vi_val, sai, sbi, psb[j]);
                     const float v = ward_lw_value(d_ci_aj, d_ci_bj, pv[j], psa[j], psb[j], sci);
                     const int ci = (int)(n + t + vi);
-                    Dtri[rowoff[n + t + j] + ci] = v;
+                    Dtri[rowoff[n + t + j] + mcol[ai]] = v; // c_i takes over a_i's column when it commits
                     if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)ci;
                 }
             }
@@ -2633,8 +2067,8 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
         alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
         unsigned long long key = ~0ull;
         if (alive && sx + psa[j] + psb[j] <= max_size) {
-            const float v = ward_lw_value(tri_at(Dtri, rowoff, pa[j], x), tri_at(Dtri, rowoff, pb[j], x), pv[j], psa[j], psb[j], sx);
-            Dtri[rowoff[n + t + j] + x] = v;
+            const float v = ward_lw_value(tri_at(Dtri, rowoff, mcol, pa[j], x), tri_at(Dtri, rowoff, mcol, pb[j], x), pv[j], psa[j], psb[j], sx);
+            Dtri[rowoff[n + t + j] + mcol[x]] = v;
             if (v < ICL_MAXF) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
         }
         publish(j, key, survives ? key : ~0ull);
@@ -2672,17 +2106,30 @@ struct wb_map { // a tiny associative array spread over the lanes of a wave
     }
 };
 
+// Row storage of the cluster that merge q will create (file header): one of the WB_K spare rows, or the storage of a_{q-WB_K},
+// the higher-position member of the merge committed WB_K merges earlier.  t0 / a0: the merges [t0, t0 + J) were committed by the
+// calling kernel itself (their log entries may not be readable yet): a0[i] is the a of merge t0 + i.  q - WB_K < t0 + J always
+// holds: a batch starts at the committed count and holds at most WB_K picks.
+__device__ __forceinline__ int64_t ward_new_row(int64_t n, int64_t ld, int q, int t0, const int32_t *a0, const int32_t *merges, const int64_t *rowoff)
+{
+    if (q < WB_K) return (n + q) * ld;
+    const int p = q - WB_K;
+    const int a = p >= t0 ? a0[p - t0] : merges[3 * p];
+    return rowoff[a];
+}
+
 #define WB_FIN_THREADS 512
 __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow,
                                                                 float *__restrict__ cnewK, int64_t cn_stride, int32_t *__restrict__ slot_id,
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
                                                                 float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                                                 int32_t *__restrict__ merges, float *__restrict__ Dtri,
-                                                                const int64_t *__restrict__ rowoff, int max_size, ward_state *__restrict__ st, int lw,
+                                                                int64_t *__restrict__ rowoff, int32_t *__restrict__ mcol, int32_t *__restrict__ msz,
+                                                                int32_t *__restrict__ mcid, int64_t ld, int max_size, ward_state *__restrict__ st, int lw,
                                                                 int32_t *__restrict__ fdrec)
 {
-    // fdrec != nullptr: the express path's data phase runs in ward_finish_data_kernel (several workgroups) from the record
-    // written here; nullptr: it runs below on this one workgroup (ICL_WARD_FD=0, A/B switch)
+    // fdrec: the express path's data phase runs in ward_finish_data_kernel (several workgroups) from the record written here
+    // (nullptr -- FAST mode, or d % 4 != 0 -- never takes the express path's data phase)
     if (fdrec && threadIdx.x == 0) fdrec[0] = 0;
     // lw != 0 (FAST mode): the rows come from the Lance-Williams recurrence, no centroid is kept: only the bookkeeping runs
     __shared__ float sv[16];
@@ -2806,6 +2253,15 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             asz[a] = 0;
             asz[b] = 0;
             asz[c] = ls.B.sa[j] + ls.B.sb[j];
+            {
+                // recycled storage (file header): c takes over a's column, b's column dies.  The picks of a batch are pairwise
+                // disjoint, so the lanes touch different columns.
+                const int ca = mcol[a], cb = mcol[b];
+                mcol[c] = ca;
+                msz[ca] = ls.B.sa[j] + ls.B.sb[j];
+                mcid[ca] = c;
+                msz[cb] = 0;
+            }
             rowmin[a] = ICL_MAXF;
             rowmin[b] = ICL_MAXF;
             rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
@@ -2908,6 +2364,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.val[j] = ls.B.pre_val[j];
                         st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
+                        rowoff[n + t1 + j] = ward_new_row(n, ld, t1 + j, t0, ls.B.a, merges, rowoff);
                     } else if (lane >= WB_K && lane < WB_K + np)
                         pk_slb[lane - WB_K] = srcsel;
                     if (lane == 0) {
@@ -2955,86 +2412,6 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             fdrec[4] = sh[5];
             fdrec[0] = 1;
         }
-        return;
-    }
-    if (sh[2]) {
-        // one data phase, one k-group per thread: centroid images of the committed clusters (cnew_j into a's slot, THEN
-        // the compaction move) and the merged centroids of the next batch (clustering.go:37-40), in chunks of 8
-        // commits / picks so that every load of a chunk is in flight at once.  The express path is only taken when
-        // nothing reads a slot written here (sh[3] == 0), so the chunks are independent; every old cnew row is read
-        // before any new one is written (same thread, same addresses: program order).
-        const int np = npk;
-        const int g = threadIdx.x;
-        const unsigned long long deadm = ((unsigned long long)(unsigned)sh[5] << 32) | (unsigned)sh[4]; // records overwritten later
-        if (g < (d >> 2)) {
-            constexpr int CH = 8;
-            // Named values, not arrays: hipcc keeps float4 arrays of this size in scratch memory here, and without the
-            // fence it sinks every load next to its store (load, wait, store, ...), serialising the round trips.
-            auto chunk = [&](const int c0) {
-                const float *dummy = cnewK; // unused entries read a valid row: straight-line code
-                auto ld_w = [&](int r) { // write record r of this chunk: even = cnew_j -> slot_a_j, odd = content of from_j -> to_j
-                    const int j = c0 + (r >> 1);
-                    const float *src = dummy;
-                    if (j < J) {
-                        if (r & 1) {
-                            const int fr = cm_from[j];
-                            if (fr >= 0) src = Crow + (int64_t)fr * d;
-                        } else
-                            src = cnewK + j * cn_stride;
-                    }
-                    return reinterpret_cast<const float4 *>(src)[g];
-                };
-                auto st_w = [&](int r, const float4 &v) {
-                    const int j = c0 + (r >> 1);
-                    if (j >= J) return;
-                    const int sr = (r & 1) ? cm_to[j] : cm_slot_a[j];
-                    if (sr < 0 || ((deadm >> (2 * c0 + r)) & 1ull)) return;
-                    reinterpret_cast<float4 *>(Crow + (int64_t)sr * d)[g] = v;
-                    if (g < 2 * WB_SG) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sr)) = v;
-                };
-                auto ld_p = [&](int q, bool second) { // centroid of a member of pick c0+q
-                    const int j = c0 + q;
-                    const float *src = dummy;
-                    if (j < np) {
-                        const int sel = second ? pk_slb[j] : pk_sla[j]; // >= 0: Crow slot; < 0: old cnew row -1-sel
-                        src = sel >= 0 ? Crow + (int64_t)sel * d : cnewK + (int64_t)(-1 - sel) * cn_stride;
-                    }
-                    return reinterpret_cast<const float4 *>(src)[g];
-                };
-                auto st_p = [&](int q, const float4 &av, const float4 &bv) {
-                    const int j = c0 + q;
-                    if (j >= np) return;
-                    const float fa = (float)pk_sa[j], fb = (float)pk_sb[j], fs = (float)(pk_sa[j] + pk_sb[j]);
-                    float4 o;
-                    { const float pa = fa * av.x; const float pb = fb * bv.x; const float sm = pa + pb; o.x = sm / fs; }
-                    { const float pa = fa * av.y; const float pb = fb * bv.y; const float sm = pa + pb; o.y = sm / fs; }
-                    { const float pa = fa * av.z; const float pb = fb * bv.z; const float sm = pa + pb; o.z = sm / fs; }
-                    { const float pa = fa * av.w; const float pb = fb * bv.w; const float sm = pa + pb; o.w = sm / fs; }
-                    reinterpret_cast<float4 *>(cnewK + j * cn_stride)[g] = o;
-                };
-#define WB_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-#define WB_REP16(M) WB_REP8(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
-#define WB_LDW(r) const float4 w##r = ld_w(r);
-#define WB_LDP(q) const float4 a##q = ld_p(q, false), b##q = ld_p(q, true);
-#define WB_STW(r) st_w(r, w##r);
-#define WB_STP(q) st_p(q, a##q, b##q);
-                WB_REP16(WB_LDW)
-                WB_REP8(WB_LDP)
-                asm volatile("" ::: "memory");
-                WB_REP16(WB_STW)
-                WB_REP8(WB_STP)
-#undef WB_LDW
-#undef WB_LDP
-#undef WB_STW
-#undef WB_STP
-            };
-            static_assert(CH == 8, "the chunk macros expand 8 commits / picks");
-            const int cmax = J > np ? J : np;
-            chunk(0);
-            if (WB_K > CH && CH < cmax) chunk(CH);
-            static_assert(WB_K <= 2 * CH, "two chunks");
-        }
-        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
         return;
     }
     if (lw) {
@@ -3136,8 +2513,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 const unsigned long long key = ls.B.ckey[j];
                 if (key != ~0ull) {
                     const int x = (int)(key & 0xffffffffu);
-                    bool died = x == ls.B.a[j]; // a pruned row's key carries its own (dead) member a_j: a bound only, to be refined
-                    for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]); // or its minimum partner was merged later in the same batch
+                    bool died = false;
+                    for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]); // its minimum partner was merged later in the same batch
                     crow[j] = (int)(n + t0 + j);
                     cnn[j] = died ? -2 : x;
                     cval[j] = __uint_as_float((unsigned)(key >> 32));
@@ -3302,10 +2679,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             float rv;
             int ri;
             {
-                // rows written by the pruning update kernel may hold flagged lower bounds: refine on demand (no exclusions here)
-                const wrefine rf{Crow, id_slot, d, bi, &st->B.refined};
                 const int noex[1] = {-1};
-                scan_row_ex(Dtri + rowoff[bi], bi, asz, asz[bi], max_size, noex, 0, rv, ri, (WX_PRUNE && !lw) ? &rf : nullptr, sv, si);
+                scan_row_m(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri);
             }
             block_argmin(rv, ri, sv, si);
             if (threadIdx.x == 0) {
@@ -3346,6 +2721,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             st->B.val[j] = pk_v[j];
             st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
             rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
+            rowoff[n + t + j] = ward_new_row(n, ld, t + j, t0, ls.B.a, merges, rowoff);
         }
         if (j == 0) {
             st->B.nb = np;
@@ -3416,34 +2792,54 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+// ---- the transport format of distance rows between GPUs: spans of the PACKED lower triangle (row r holds r floats, padded to 4)
+__host__ __device__ static inline int64_t tri_rowoff(int64_t r) // float offset of row r: rows are padded to 4 floats -> sum_{q<r} 4*ceil(q/4)
+{
+    // row 0 holds nothing, rows 4k+1 .. 4k+4 hold 4(k+1) floats each: sum over rows 1 .. r-1 = full groups of four + the partial group
+    if (r <= 0) return 0;
+    const int64_t q = r - 1, g = q / 4, p = q % 4;
+    return 16 * g * (g + 1) / 2 + p * 4 * (g + 1);
+}
+
+// packed span of rows [row_lo, row_hi) -> the rows of the matrix (one workgroup per row; both sides are 16-byte aligned and
+// a packed row's padding lands in cells right of the diagonal, which no scan ever accepts)
+__global__ __launch_bounds__(256) void ward_unpack_span_kernel(const float *__restrict__ span, int64_t row_lo, int64_t row_hi, float *__restrict__ D, int64_t ld)
+{
+    const int64_t base = tri_rowoff(row_lo);
+    for (int64_t r = row_lo + blockIdx.x; r < row_hi; r += gridDim.x) {
+        const float4 *src = reinterpret_cast<const float4 *>(span + (tri_rowoff(r) - base));
+        float4 *dst = reinterpret_cast<float4 *>(D + r * ld);
+        const int64_t nv = (r + 3) >> 2;
+        for (int64_t q = threadIdx.x; q < nv; q += blockDim.x) dst[q] = src[q];
+    }
+}
+
 static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
 {
     if (!ctx->ward) ctx->ward = new icl_ward_ws();
     icl_ward_ws *w = ctx->ward;
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
-        void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->Dtri,
-                        w->merges, w->st};
+        void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
+                        w->Dtri, w->merges, w->st};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
+        for (auto &sp : w->staged)
+            if (sp.second) (void)hipFree(sp.second);
+        w->staged.clear();
         if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
         w->graph_exec = nullptr;
         w->CT = w->Crow = w->cnew = w->cnewI = w->rowmin = w->Dtri = nullptr;
-        w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = nullptr;
+        w->slot_id = w->id_slot = w->asz = w->rownn = w->merges = w->mcol = w->msz = w->mcid = nullptr;
         w->rowoff = nullptr;
         w->st = nullptr;
         w->capN = 0;
         w->S = (n + 63) / 64 * 64;
         if (w->S == 0) w->S = 64;
-        w->M = 2 * n + 4; // padded so int4 mask loads on any row prefix stay in bounds
+        w->M = 2 * n + 4; // creation ids: n singletons + at most n - 1 merged clusters (padded: rowmin is read in groups of four)
         w->M = (w->M + 3) / 4 * 4;
-        w->h_rowoff.resize((size_t)w->M + 1);
-        int64_t off = 0;
-        for (int64_t r = 0; r <= w->M; ++r) {
-            w->h_rowoff[(size_t)r] = off;
-            off += (r + 3) / 4 * 4;
-        }
-        w->dtri_floats = off;
+        w->ld = w->S; // row pitch: a multiple of 64 floats, so every row starts 256-byte aligned
+        w->dtri_floats = (n + WB_K) * w->ld;
         const int64_t dd = d > 0 ? d : 1;
 #define WS_ALLOC(field, type, count)                                                                             \
     do {                                                                                                         \
@@ -3467,11 +2863,12 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rowmin, float, w->M);
         WS_ALLOC(rownn, int32_t, w->M);
         WS_ALLOC(rowoff, int64_t, w->M + 1);
+        WS_ALLOC(mcol, int32_t, w->M);
+        WS_ALLOC(msz, int32_t, w->ld);
+        WS_ALLOC(mcid, int32_t, w->ld);
         WS_ALLOC(Dtri, float, w->dtri_floats);
         WS_ALLOC(merges, int32_t, 3 * n + 3);
         WS_ALLOC(st, ward_state, 1);
-        ICL_HIP(ctx, hipMemcpyAsync(w->rowoff, w->h_rowoff.data(), (size_t)(w->M + 1) * sizeof(int64_t),
-                                    hipMemcpyHostToDevice, ctx->stream));
         ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         w->capN = n;
         w->capD = d;
@@ -3729,9 +3126,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     ICL_HIP(ctx, hipEventRecord(e0, ctx->stream));
 
     {
-        const int64_t cnt = std::max(w->S, w->M);
-        hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, ctx->stream, n, w->S, w->M,
-                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->st, (int32_t)T);
+        const int64_t cnt = std::max(std::max(w->S, w->M), w->ld);
+        hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, ctx->stream, n, w->S, w->M, w->ld,
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)T);
         if (d > 0) {
             hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)icl_ceil_div(w->S, 32), (unsigned)icl_ceil_div((d + 3) / 4, 32)), dim3(256), 0,
                                ctx->stream, d_E, n, d, w->S, w->CT);
@@ -3739,7 +3136,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         }
         ICL_HIP(ctx, hipGetLastError());
     }
-    // ComputeInitialDistanceMatrix (clustering.go:217) into the packed triangle: exact tile, or the MFMA tile in FAST mode
+    // ComputeInitialDistanceMatrix (clustering.go:217) into the singleton rows: exact tile, or the MFMA tile in FAST mode
     if (own_hi < 0) own_hi = n;
     if (own_lo < 0 || own_lo > own_hi || own_hi > n || own_lo % DT_TILE || (own_hi % DT_TILE && own_hi != n))
         return icl_fail(ctx, ICL_ERR_ARG, "own rows [%lld, %lld) must be whole 128-row tile rows of [0, %lld)", (long long)own_lo, (long long)own_hi, (long long)n);
@@ -3748,11 +3145,18 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ICL_TRY(icl_dist_mfma_launch(ctx, d_E, n, d, w->Dtri, w->rowoff, 0));
     } else
         ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0, own_lo / DT_TILE, icl_ceil_div(own_hi, DT_TILE)));
+    // rows computed elsewhere (other GPUs) arrived in the transport format -- spans of the packed lower triangle -- and are
+    // laid out into the matrix rows here
+    for (auto &sp : w->staged) {
+        const int64_t lo = sp.first.first, hi = std::min<int64_t>(sp.first.second, n);
+        if (hi <= lo) continue;
+        hipLaunchKernelGGL(ward_unpack_span_kernel, dim3((unsigned)std::min<int64_t>(hi - lo, 65535)), dim3(256), 0, ctx->stream, sp.second, lo, hi, w->Dtri, w->ld);
+    }
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
-        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, max_size,
-                           n, w->rowmin, w->rownn);
+        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, w->msz, w->mcid,
+                           max_size, n, w->rowmin, w->rownn);
         ICL_HIP(ctx, hipGetLastError());
     }
     ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -3764,24 +3168,23 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const int dqp = (int)upd_groups(d);
     const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16 + (size_t)2 * UPD_SG * 64 * 16; // new centroid image + p ring
     if (upd_lds > 160 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
-    static bool upd_attr = false;
-    if (!upd_attr) {
+    if (!w->upd_attr) { // per context, i.e. per device
         (void)hipFuncSetAttribute((const void *)ward_update_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        upd_attr = true;
+        w->upd_attr = true;
     }
     auto finish = [&]() {
         hipLaunchKernelGGL(ward_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
-                           w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->st);
+                           w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->rowoff, w->mcol, w->msz, w->mcid, w->ld, w->st);
     };
     const unsigned lw_blocks = (unsigned)icl_ceil_div(w->S, UPD_THREADS) + 1;
     auto launch_update = [&]() {
         if (lw) {
-            hipLaunchKernelGGL(ward_update_lw_kernel, dim3(lw_blocks), dim3(UPD_THREADS), 0, ctx->stream, w->slot_id, w->asz, w->rowoff, w->Dtri,
-                               w->st, max_size, n, w->rowmin, w->rownn);
+            hipLaunchKernelGGL(ward_update_lw_kernel, dim3(lw_blocks), dim3(UPD_THREADS), 0, ctx->stream, w->slot_id, w->asz, w->rowoff, w->mcol, w->msz,
+                               w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
             return;
         }
         hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(UPD_THREADS), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
-                           w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+                           w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
     };
     // one step: update(t) [with preselect(t+1) as one of its workgroups] -> finish(t+1)
     auto enqueue_step = [&](int64_t t, bool prof) {
@@ -3807,67 +3210,35 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // each chunk, one chunk behind the launches so the queue never drains.
         const int dqb = (int)wb_groups(d);
         const unsigned lw_blocks_b = (unsigned)icl_ceil_div(w->S, WB_THREADS) + 2 + WB_R;
-        const size_t wb_lds_bytes = (size_t)2 * (WB_PRING ? WB_KC : 1) * WB_SG * 64 * 16 + (size_t)WB_KC * dqb * 16;
-        const unsigned wb_blocks = (unsigned)((w->S / 64 + 7) / 8 * 8) * WB_NH + 1 + WB_NH + WB_R; // + spare re-minimisers + preselection + virtual slots
-        // ICL_WARD_UPD=1 selects the first-generation kernel (WB_NH workgroups per slot block) for A/B measurements
-        static const bool gen2 = [] {
-            const char *e = getenv("ICL_WARD_UPD");
-            return !(e && e[0] == '1');
-        }();
-        if (!lw && !gen2) { // first-generation kernel only: its LDS holds whole centroid images
-            if (wb_lds_bytes > 150 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the first-generation update kernel's LDS image", d);
-            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb_lds_bytes));
-        }
         const size_t wx_lds_bytes = (size_t)WX_R * WX_STAGE_F4 * 16;
-        // ICL_WARD_PRUNE=<beta>: partial-sum pruning (tau = beta x the batch's largest pick value).  OFF by default: exact and
-        // parity-green (every large-N test passes with it), and it cuts the update workgroup from 45 to 31 us (98 % of the chain
-        // waves stop within 3 of 32 stages), but rows that become ISOLATED -- their near partners are gone, the next candidate
-        // is 100x farther -- must later be made exact entry by entry on one workgroup (1.2e8 refined entries at N = 100 000:
-        // merge loop 1.5 s -> 20 s on the mixture-of-Gaussians input, 3.1 s on the ResNet embeddings).  It pays only once such
-        // rows are re-bounded in batches by the update kernel itself.
-        static const float wx_prune = [] {
-            const char *e = getenv("ICL_WARD_PRUNE");
-            const float b = e ? (float)atof(e) : 0.0f;
-            return (WX_PRUNE && b >= 1.0f) ? b : 0.0f;
-        }();
-        static const int wx_diag = [] { // ICL_WX_DIAG: 1 = no chain arithmetic, 2 = no column loads (kernel timing experiments; WRONG results)
-            const char *e = getenv("ICL_WX_DIAG");
-            return e ? atoi(e) : 0;
-        }();
         // main workgroups: persistent, at most one per CU (they draw blocks from a counter); fewer when the input has fewer blocks
-        const unsigned wx_blocks = (unsigned)std::min<int64_t>((w->S / 64 + WX_NS - 1) / WX_NS, (int64_t)WX_WGS_PER_CU * ctx->prop.multiProcessorCount) + 2 + WB_R;
-        static bool wx_attr = false;
-        if (!wx_attr) {
+        const unsigned wx_blocks = (unsigned)std::min<int64_t>(w->S / 64, (int64_t)ctx->prop.multiProcessorCount) + 2 + WB_R;
+        if (!w->wx_attr) { // per context, i.e. per device: a group drives one context per GPU
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
-            wx_attr = true;
+            w->wx_attr = true;
         }
-        static const bool fd_split = [] { // ICL_WARD_FD=0: the express data phase stays inside the finish kernel (A/B switch)
-            const char *e = getenv("ICL_WARD_FD");
-            return !(e && e[0] == '0');
-        }();
-        int32_t *fdrec = (!lw && gen2 && fd_split && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
+        // the express step's data phase runs in ward_finish_data_kernel from a record the finish kernel leaves behind cnewI
+        int32_t *fdrec = (!lw && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
-                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, max_size, w->st, lw ? 1 : 0, fdrec);
+                               w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, w->mcol, w->msz, w->mcid, w->ld, max_size,
+                               w->st, lw ? 1 : 0, fdrec);
             if (fdrec) // the express step's data phase on several CUs, the pair-interleaved copy of the new centroids, the block counter reset
                 hipLaunchKernelGGL(ward_finish_data_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, WB_FD_THREADS)), dim3(WB_FD_THREADS), 0,
                                    ctx->stream, d, w->S, w->CT, w->Crow, w->cnew, w->cnewI, w->cn_stride, fdrec, w->st);
-            else if (!lw && gen2) // the pair-interleaved copy of the centroids the finish kernel has just written + the block counter reset
+            else if (!lw) // (d % 4 != 0) the pair-interleaved copy of the centroids the finish kernel has just written + the block counter reset
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
                                    w->cn_stride, w->cnewI, w->st);
         };
         auto update_b = [&]() {
             if (lw) {
                 hipLaunchKernelGGL(ward_update_batch_lw_kernel, dim3(lw_blocks_b), dim3(WB_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff,
-                                   w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+                                   w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
                 return;
             }
-            if (gen2)
-                hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
-                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, wx_diag, wx_prune);
-            else
-                hipLaunchKernelGGL(ward_update_batch_kernel, dim3(wb_blocks), dim3(WB_THREADS), wb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
-                                   w->cnew, w->cn_stride, w->slot_id, w->asz, w->rowoff, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+            hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+                               w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
+                               w->rowmin, w->rownn);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -3880,11 +3251,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             finish_b();
         };
         finish_b(); // first batch: one pick by the plain lazy selection
-        static const bool graph_env = [] { // ICL_WARD_GRAPH=0: eager launches (diagnostic switch: profilers that cannot follow a graph replay)
-            const char *e = getenv("ICL_WARD_GRAPH");
-            return !(e && e[0] == '0');
-        }();
-        const bool use_graph = graph_env && !prof_update && T >= 2 * GRAPH_STEPS;
+        const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
         if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2))) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
@@ -3926,7 +3293,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         if (rc_b == ICL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc_b = ICL_ERR_HIP;
         if (rc_b != ICL_OK) return icl_fail(ctx, ICL_ERR_HIP, "batched merge loop: %s", hipGetErrorString(hipGetLastError()));
     } else {
-    hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff,
+    hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff, w->msz, w->mcid,
                        max_size, w->st); // merge 0 has no update in front of it
     finish();
     if (prof_update || T < 2 * GRAPH_STEPS) {
@@ -3953,6 +3320,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 
     ICL_HIP(ctx, hipMemcpyAsync(&hst, w->st, sizeof hst, hipMemcpyDeviceToHost, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sp : w->staged)
+        if (sp.second) (void)hipFree(sp.second);
+    w->staged.clear();
     // The loop ends when len(clusters) == k or no mergeable pair is left (clustering.go:220-225).  Anything else -- the chunk
     // budget of the batched loop ran out, a replay did nothing -- is an engine failure, never a shorter clustering.
     if (!(hst.done || hst.t >= T))
@@ -3962,8 +3332,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
                 hst.B.slow, hst.B.general);
-    if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] pruning: %llu of %llu chain waves stopped early; %llu entries refined on demand\n", hst.B.pruned_waves, hst.B.chain_waves, hst.B.refined);
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
 #ifdef ICL_WARD_TIMERS
@@ -4010,18 +3378,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 }
 
 // ---- distance tiles over several GPUs ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI") ----------
-// The packed triangle stores its rows back to back, so a run of rows [lo, hi) is ONE contiguous span of floats: a GPU
-// computes the span of its own rows into a buffer of that size and the span is copied (peer copy / RCCL send) to the same
-// offset of the clustering GPU's triangle.  Rows are dealt in whole 128-row tile rows, balanced by AREA (tile row ti
-// has ti+1 tiles), not by row count.
-static int64_t tri_rowoff(int64_t r) // float offset of row r: rows are padded to 4 floats -> sum_{q<r} 4*ceil(q/4)
-{
-    // row 0 holds nothing, rows 4k+1 .. 4k+4 hold 4(k+1) floats each: sum over rows 1 .. r-1 = full groups of four + the partial group
-    if (r <= 0) return 0;
-    const int64_t q = r - 1, g = q / 4, p = q % 4;
-    return 16 * g * (g + 1) / 2 + p * 4 * (g + 1);
-}
-
+// A packed lower triangle stores its rows back to back, so a run of rows [lo, hi) is ONE contiguous span of floats: a GPU
+// computes the span of its own rows into a buffer of that size, the span travels as it is (peer copy / RCCL send: every byte
+// is a distance, nothing is padded to the matrix pitch) into a staging buffer of the clustering GPU, and the next cluster call
+// lays the staged spans out into the matrix rows (ward_unpack_span_kernel).  Rows are dealt in whole 128-row tile rows,
+// balanced by AREA (tile row ti has ti+1 tiles), not by row count.
 extern "C" int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi)
 {
     if (n < 0 || parts < 1 || part < 0 || part >= parts || !row_lo || !row_hi) return icl_fail(nullptr, ICL_ERR_ARG, "icl_ward_rows_partition: bad argument");
@@ -4074,28 +3435,67 @@ extern "C" int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d)
     return ward_ensure(ctx, n, d);
 }
 
+// Where rows [row_lo, row_hi) computed elsewhere are to be delivered on this GPU: a staging buffer in the transport format
+// (allocated on first request, owned by the context, consumed and released by the next icl_cluster_prefilled_dev).
+static int ward_stage_locked(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, float **out, int64_t *cnt)
+{
+    icl_ward_ws *w = ctx->ward;
+    if (!w || !w->Dtri || row_hi > w->capN) return icl_fail(ctx, ICL_ERR_ARG, "call icl_ward_prepare(n, d) before delivering distance rows");
+    *cnt = tri_rowoff(row_hi) - tri_rowoff(row_lo);
+    for (auto &sp : w->staged)
+        if (sp.first.first == row_lo && sp.first.second == row_hi) {
+            *out = sp.second;
+            return ICL_OK;
+        }
+    float *p = nullptr;
+    if (hipMalloc((void **)&p, (size_t)std::max<int64_t>(*cnt, 4) * 4) != hipSuccess)
+        return icl_fail(ctx, ICL_ERR_NOMEM, "staging buffer for distance rows [%lld, %lld): %lld floats", (long long)row_lo, (long long)row_hi, (long long)*cnt);
+    try {
+        w->staged.push_back({{row_lo, row_hi}, p});
+    } catch (...) {
+        (void)hipFree(p);
+        return icl_fail(ctx, ICL_ERR_NOMEM, "out of host memory");
+    }
+    *out = p;
+    return ICL_OK;
+}
+
 extern "C" int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt)
 {
     if (!ctx || !d_ptr || !float_cnt || row_lo < 0 || row_hi < row_lo) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_span_ptr: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!ctx->ward || !ctx->ward->Dtri || row_hi > ctx->ward->capN) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_span_ptr: call icl_ward_prepare(n, d) first");
-    *d_ptr = ctx->ward->Dtri + tri_rowoff(row_lo);
-    *float_cnt = tri_rowoff(row_hi) - tri_rowoff(row_lo);
+    icl_device_guard g(ctx->device);
+    float *p = nullptr;
+    ICL_TRY(ward_stage_locked(ctx, row_lo, row_hi, &p, float_cnt));
+    *d_ptr = p;
     return ICL_OK;
 }
 
-// Copies a span computed elsewhere (this or another GPU: peer copy) into the triangle.
+// Copies a span computed elsewhere (this or another GPU: a peer copy over xGMI when the devices are peers) into the staging
+// buffer of its rows.  The context's mutex is held only while the buffer is looked up: the copy runs on a stream of its own, so
+// the spans of several GPUs arrive concurrently (one link each) while this GPU computes its own rows.
 extern "C" int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span)
 {
-    void *dst = nullptr;
+    if (!ctx || row_lo < 0 || row_hi < row_lo) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_deposit_dev: bad argument");
+    float *dst = nullptr;
     int64_t cnt = 0;
-    ICL_TRY(icl_ward_span_ptr(ctx, row_lo, row_hi, &dst, &cnt));
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        icl_device_guard g(ctx->device);
+        ICL_TRY(ward_stage_locked(ctx, row_lo, row_hi, &dst, &cnt));
+    }
     if (cnt == 0) return ICL_OK;
     if (!d_span) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_deposit_dev: null span");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
-    ICL_HIP(ctx, hipMemcpyAsync(dst, d_span, (size_t)cnt * 4, hipMemcpyDefault, ctx->stream));
-    ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t cs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_span, (size_t)cnt * 4, hipMemcpyDefault, cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        return icl_fail(ctx, ICL_ERR_HIP, "icl_ward_deposit_dev: copy of rows [%lld, %lld) failed: %s", (long long)row_lo, (long long)row_hi, hipGetErrorString(e));
+    }
     return ICL_OK;
 }
 

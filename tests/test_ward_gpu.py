@@ -253,7 +253,7 @@ def test_every_small_case_against_both_oracles(ctx, name, E, mn, mx):
 
 
 def test_large_n_creation_ids_past_40960(ctx):
-    """N=24 000, D=16, min=5 max=50: 21 360 merges, creation ids (rows of the packed triangle) up to 45 359.  The batched
+    """N=24 000, D=16, min=5 max=50: 21 360 merges, creation ids up to 45 359 (rows and columns of the matrix recycled ~21 000 times).  The batched
     update's spare workgroups once dropped rows >= 40 960 silently (16-iteration hit mask); ids, member order, the merge
     log and every merge value must equal the oracle's."""
     f = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
@@ -261,7 +261,7 @@ def test_large_n_creation_ids_past_40960(ctx):
 
 
 def test_large_n_creation_ids_past_65536(ctx):
-    """N=45 000, D=8: 40 050 merges, creation ids up to 85 049 (past 2^16), 14.5 GB triangle."""
+    """N=45 000, D=8: 40 050 merges, creation ids up to 85 049 (past 2^16), 8 GB distance matrix."""
     f = same_as_fast_oracle(ctx, WC.mog(45000, 8, 2), 5, 50)
     assert f["merges"] == 40050
 
@@ -288,56 +288,12 @@ def test_large_n_wide_rows_workgroups_run_several_blocks(ctx):
 
 
 def test_config2_full_size_properties_100k(ctx):
-    """BASELINE.json's metric size: N=100 000, D=2048, min=5 max=50 (k=11 000, 89 000 merges, 80 GB triangle).  No CPU
-    oracle reaches this size: size-independent properties + idempotence."""
-    import torch
+    """BASELINE.json's metric size: N=100 000, D=2048, min=5 max=50 (k=11 000, 89 000 merges, 40 GB distance matrix).  No CPU
+    oracle reaches this size: size-independent properties, spot-checked merge values, idempotence (tests/ward_props.py)."""
+    from tests.ward_props import check_full_size_run
 
-    n, d = 100000, 2048
-    g = torch.Generator(device="cuda")
-    g.manual_seed(20250217)
-    cen = torch.randn((n // 20, d), generator=g, device="cuda")
-    lab = torch.randint(0, n // 20, (n,), generator=g, device="cuda")
-    E = (cen[lab] + 0.1 * torch.randn((n, d), generator=g, device="cuda")).contiguous()
-    del cen
-    torch.cuda.synchronize()
-    cid, rank, nc = ctx.cluster_dev(E.data_ptr(), n, d, 5, 50)
-    m = ctx.last_merges()
-    v = ctx.last_merge_values()
-    assert len(m) == 89000 == n - O.calc_optimal_clusters(n, 5, 50)[0]
-    kept = cid[cid >= 0]
-    counts = np.bincount(kept)
-    assert sorted(set(kept.tolist())) == list(range(nc)) and counts.min() >= 5 and counts.max() <= 50
-    order = np.lexsort((rank, cid))
-    o = order[cid[order] >= 0]
-    starts = np.r_[0, np.cumsum(counts)[:-1]]
-    assert np.array_equal(rank[o], np.arange(len(o)) - np.repeat(starts, counts))
-    # the merge log is a valid agglomeration over creation ids: both sides alive, a = the later-created one
-    alive = np.ones(n + len(m), bool)
-    alive[n:] = False
-    size = np.ones(n + len(m), np.int64)
-    for t, (a, b) in enumerate(m.tolist()):
-        assert a > b and alive[a] and alive[b], t
-        alive[a] = alive[b] = False
-        alive[n + t] = True
-        size[n + t] = size[a] + size[b]
-        assert size[n + t] <= 50
-    assert np.isfinite(v).all() and (v >= 0).all()
-    # spot-check merge values against the oracle's arithmetic: singleton-singleton merges can be recomputed from E alone
-    Eh = {}
-    checked = 0
-    for t, (a, b) in enumerate(m[:4000].tolist()):
-        if a < n and b < n:
-            for x in (a, b):
-                if x not in Eh:
-                    Eh[x] = E[x].cpu().numpy()
-            assert np.float32(v[t]).view(np.uint32) == O.ward_distance(Eh[a], 1, Eh[b], 1).view(np.uint32), t
-            checked += 1
-            if checked == 200:
-                break
-    assert checked > 50
-    # idempotence
-    cid2, rank2, nc2 = ctx.cluster_dev(E.data_ptr(), n, d, 5, 50)
-    assert nc2 == nc and np.array_equal(cid, cid2) and np.array_equal(rank, rank2) and np.array_equal(ctx.last_merges(), m)
+    merges, _ = check_full_size_run(ctx, 100000, 2048, 20250217, 5, 50)
+    assert merges == 89000
 
 
 def test_one_merge_per_step_pipeline_against_oracle_large_n(tmp_path):

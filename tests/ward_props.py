@@ -1,0 +1,56 @@
+"""Size-independent properties of a size-constrained Ward run at sizes no CPU restatement reaches (BASELINE.json configs[2]
+N = 100 000 and configs[4] N = 250 000, D = 2048): what PerformClusteringWithConstraints (clustering.go:198-284) guarantees
+whatever the input, plus merge values that can be recomputed from E alone with the oracle's arithmetic."""
+import numpy as np
+
+from oracle import oracle as O
+from tests.ward_pipeline_child import make_E
+
+
+def check_full_size_run(ctx, n, d, seed, mn, mx, spot=200):
+    """Clusters a seeded mixture-of-Gaussians E (built on the device) twice and checks: the merge count of
+    CalculateOptimalClusters; ids dense, sizes within [mn, mx]; member ranks a permutation per cluster; the merge log a valid
+    agglomeration over creation ids (both sides alive, a = the later-created one, sizes <= mx); merge values finite, >= 0 and,
+    for singleton-singleton merges, bit-equal to the oracle's WardDistance of the two rows of E; idempotence."""
+    E = make_E(n, d, seed)
+    cid, rank, nc = ctx.cluster_dev(E.data_ptr(), n, d, mn, mx)
+    m = ctx.last_merges()
+    v = ctx.last_merge_values()
+    k = O.calc_optimal_clusters(n, mn, mx)[0]
+    assert len(m) == n - k
+    kept = cid[cid >= 0]
+    counts = np.bincount(kept)
+    assert nc == len(counts) and (counts > 0).all() and counts.min() >= mn and counts.max() <= mx
+    order = np.lexsort((rank, cid))
+    o = order[cid[order] >= 0]
+    starts = np.r_[0, np.cumsum(counts)[:-1]]
+    assert np.array_equal(rank[o], np.arange(len(o)) - np.repeat(starts, counts))
+    alive = np.ones(n + len(m), bool)
+    alive[n:] = False
+    size = np.ones(n + len(m), np.int64)
+    for t, (a, b) in enumerate(m.tolist()):
+        assert a > b and alive[a] and alive[b], t
+        alive[a] = alive[b] = False
+        alive[n + t] = True
+        size[n + t] = size[a] + size[b]
+        assert size[n + t] <= mx
+    # clusters that were dropped (< mn) are exactly the live clusters below the minimum size
+    live_sizes = size[alive]
+    assert (live_sizes >= mn).sum() == nc and int(live_sizes[live_sizes < mn].sum()) == int((cid < 0).sum())
+    assert np.isfinite(v).all() and (v >= 0).all()
+    Eh = {}
+    checked = 0
+    for t, (a, b) in enumerate(m[:6000].tolist()):
+        if a < n and b < n:
+            for x in (a, b):
+                if x not in Eh:
+                    Eh[x] = E[x].cpu().numpy()
+            assert np.float32(v[t]).view(np.uint32) == O.ward_distance(Eh[a], 1, Eh[b], 1).view(np.uint32), t
+            checked += 1
+            if checked == spot:
+                break
+    assert checked > 50
+    cid2, rank2, nc2 = ctx.cluster_dev(E.data_ptr(), n, d, mn, mx)
+    assert nc2 == nc and np.array_equal(cid, cid2) and np.array_equal(rank, rank2) and np.array_equal(ctx.last_merges(), m)
+    assert np.array_equal(ctx.last_merge_values().view(np.uint32), v.view(np.uint32))
+    return len(m), nc
