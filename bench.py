@@ -6,11 +6,13 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
     -> size-constrained Ward (min=5, max=50, exact update: cluster ids bit-identical to the reference)
     -> cluster_id[N] on the host.
 The workload is the one BASELINE.json's metric is quoted on: "images/sec (embed+Ward) on 100k 224x224 imgs at 1/2/4/8
-MI355X" -- 100 000 synthetic images (configs[2]'s N; it fits one 288 GB GPU: 15 GB of images, 80 GB distance triangle).
+MI355X" -- 100 000 synthetic images (configs[2]'s N; it fits one 288 GB GPU: 15 GB of images, 40 GB distance matrix).
 N=1 runs the whole job on one GPU; N>1 STRONG-scales the same 100 000-image job: the images are sharded over the ranks
 for the embed, E is all-gathered, every rank computes its share of the initial distance matrix and sends it to rank 0
 over xGMI, rank 0 runs the exact merge loop (configs[2]'s shape: "Ward on GPU0").  `--total-images 10000` is
-configs[1] (its line is quoted in README.md); `--scaling weak` keeps --images-per-gpu images PER GPU instead.
+configs[1] (its line is quoted in README.md), `--total-images 250000` configs[4] (250 GB distance matrix on one GPU),
+`--embed-only --total-images 1000000` configs[3]; `--scaling weak` keeps --images-per-gpu images PER GPU instead;
+`--prec fp32` runs the parity embedding (f32 MFMA, <= 1e-4 of the fp32 restatement) instead of the bf16 one.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -128,6 +130,9 @@ def main():
     ap.add_argument("--max-size", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--embed-only", action="store_true", help="configs[3]: embed throughput without clustering")
+    ap.add_argument("--prec", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16: bf16 MFMA with fp32 accumulate (BASELINE.json configs[1], the default); fp32: f32 MFMA, the parity "
+                         "path whose embeddings meet 1e-4 against the fp32 restatement (157.3 TFLOP/s matrix peak)")
     ap.add_argument("--update", choices=["exact", "lw"], default="exact",
                     help="exact: centroid recompute, cluster ids bit-identical to the reference (default); "
                          "lw: MFMA distance tile + Lance-Williams rows (fast, not bit-identical)")
@@ -176,11 +181,13 @@ def main():
     ctx.sync()
     E_local = torch.empty((max(n_local, 1), DIM), dtype=torch.float32, device=dev)[:n_local]
     update = _lib.UPDATE_LW if args.update == "lw" else _lib.UPDATE_EXACT
+    PREC = _lib.PREC_FP32 if args.prec == "fp32" else _lib.PREC_BF16
+    peak_mfma = PEAK_F32_TFLOPS if args.prec == "fp32" else PEAK_BF16_TFLOPS
     result = {}
     keep = {}
 
     def step():
-        ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), DIM, _lib.PREC_BF16)  # returns with the stream idle
+        ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), DIM, PREC)  # returns with the stream idle
         st = ctx.last_stage_ms()
         result["embed_ms"] = st["embed_ms"]
         E_full = E_local
@@ -240,7 +247,7 @@ def main():
         # at most 102 400 images (400 batches, 21 200 bracketed launches): per-launch averages do not need more, and the event
         # pairs of a pass stay allocated until it ends (configs[3] embeds 1 000 000 images)
         n_prof = min(n_local, 102400)
-        ctx.embed_u8_dev(imgs.data_ptr(), n_prof, E_local.data_ptr(), DIM, _lib.PREC_BF16)
+        ctx.embed_u8_dev(imgs.data_ptr(), n_prof, E_local.data_ptr(), DIM, PREC)
         result["embed_ms_single_stream"] = ctx.last_stage_ms()["embed_ms"] * (n_local / max(n_prof, 1))
         if embed_ms_keep is not None:
             result["embed_ms"] = embed_ms_keep
@@ -275,25 +282,30 @@ def main():
         # committed under profiles/ and quoted here.
         traffic = traffic_upd = pmc_file = None
         traffic_note = ""
-        try:  # profiles/r02c_pmc_traffic.json: scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script at the default workload)
-            pmc_file = "r02c_pmc_traffic.json"
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                pmc = json.load(f)
-            c_a, c_b = pmc["conv_igemm_kernel<BF16, 128, false, 2, true>"], pmc["conv_igemm_kernel<BF16, 128, true, 2, true>"]
-            traffic = round((c_a["hbm_bytes_per_launch"] * c_a["launches"] + c_b["hbm_bytes_per_launch"] * c_b["launches"])
-                            / (c_a["launches"] + c_b["launches"]), 0)
-            traffic_upd = round(pmc["ward_update_batch2_kernel"]["hbm_bytes_per_launch"], 0)
-            traffic_note = "(means over every launch of one bench.py run at N=100000; the ward figure includes the spare / preselection workgroups' row reads)"
-        except Exception:
-            pass
-        conv_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BF16,128>", "achieved": round(achieved, 2),
-                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        # the PMC means were taken at the default workload (100 000 images, bf16): quoted for that workload only
+        for cand in ("r03_pmc_traffic.json", "r02c_pmc_traffic.json"):  # scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script)
+            if n_total != 100000 or args.prec != "bf16":
+                break
+            try:
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    pmc = json.load(f)
+                convs = [v for k, v in pmc.items() if k.startswith("conv_igemm_kernel<BF16, 128") or k.startswith("conv3x3_halo_kernel<BF16, 128")]
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in convs) / max(sum(v["launches"] for v in convs), 1), 0)
+                traffic_upd = round(pmc["ward_update_batch2_kernel"]["hbm_bytes_per_launch"], 0)
+                traffic_note = "(means over every launch of one bench.py run at N=100000; the ward figure includes the spare / preselection workgroups' row reads)"
+                pmc_file = cand
+                break
+            except Exception:
+                continue
+        conv_roof = {"bound": "mfma", "kernel": "conv kernels with Cout >= 128 (conv_igemm_kernel<%s,128>, conv3x3_halo_kernel<%s,128>)" % ((args.prec.upper().replace("FP32", "F32"),) * 2),
+                     "achieved": round(achieved, 2),
+                     "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(achieved / peak_mfma, 4), "traffic": traffic,
                      "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
                      "algorithmic_flops_per_launch": round(c128["flops"] / max(c128["launches"], 1), 0),
                      "all_conv_achieved": round((c128["flops"] + c64["flops"]) / max(c128["ms"] + c64["ms"], 1e-9) / 1e9, 2),
-                     "embed_frac_of_bf16_peak": round(n_local * FLOP_PER_IMAGE / max(result.get("embed_ms", 0), 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
-                     "embed_frac_of_layerwise_roofline": round(layerwise_roofline_seconds(args.batch) * 1e3 * n_local / args.batch
-                                                               / max(result.get("embed_ms", 0), 1e-9), 4),
+                     "embed_frac_of_mfma_peak": round(n_local * FLOP_PER_IMAGE / max(result.get("embed_ms", 0), 1e-9) / 1e9 / peak_mfma, 4),
+                     "embed_frac_of_layerwise_roofline": (round(layerwise_roofline_seconds(args.batch) * 1e3 * n_local / args.batch
+                                                                / max(result.get("embed_ms", 0), 1e-9), 4) if args.prec == "bf16" else None),
                      "measured": "HIP events around every launch in one extra untimed single-stream pass over the same images (the timed steps keep two forward passes in flight on two streams)"}
         ward_roof = None
         if upd and upd["launches"]:
@@ -301,9 +313,14 @@ def main():
             gbs = upd["bytes"] / max(upd["ms"], 1e-9) / 1e6  # GB/s
             exact = args.update == "exact"
             tfl = upd["flops"] / max(upd["ms"], 1e-9) / 1e9  # 3 flop per (pair, k): sub, mul, add -- unfused by construction
-            ward_roof = {"bound": "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch_lw_kernel",
-                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
+            # What binds the exact update is the vector ALU (16 rows x 3 unfused fp32 ops per byte-quad: 12 flop/B), not HBM:
+            # `bound` says so, achieved / peak / frac are the vector-fp32 figures, the HBM view sits beside them in `hbm`.
+            # (The Lance-Williams update of --update lw reads 12 bytes per pair: that one IS an HBM kernel.)
+            ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch_lw_kernel",
+                         "achieved": round(tfl, 2) if exact else round(gbs, 1), "peak": PEAK_F32_TFLOPS if exact else PEAK_HBM_GBS,
+                         "unit": "TFLOP/s" if exact else "GB/s",
+                         "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
+                         "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                          "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note),
                          "launches": upd["launches"],
                          "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
@@ -312,22 +329,22 @@ def main():
                          "algorithmic_unit": "4*n_live*D bytes (one pass over the live centroids) + 4*n_live per new row, per LAUNCH; a launch "
                                              "computes the rows of up to 16 independent merges from that one pass (SURVEY.md 8d quotes "
                                              "4*n_live*D per merge: 16x these bytes)",
-                         "valu": {"achieved": round(tfl, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_F32_TFLOPS, 4),
-                                  "measured_unfused_ceiling": 61.0, "frac_of_measured_ceiling": round(tfl / 61.0, 4),
+                         "valu": {"nominal_unfused_ceiling": 78.6, "measured_unfused_ceiling": 61.0, "frac_of_measured_ceiling": round(tfl / 61.0, 4),
                                   "note": "the exact update is 3 UNFUSED fp32 ops per (new row, live cluster, k) -- the reference's rounding "
                                           "forbids FMA -- so half of the FMA-counted vector peak (78.6 TFLOP/s) is its nominal ceiling; measured "
                                           "(scratch/pk_rate_bench.hip) v_pk_add_f32 / v_pk_mul_f32 issue every 5.2-5.7 cycles against 3.2 for "
                                           "the scalar ops, i.e. unfused packed fp32 tops out at ~61 TFLOP/s on this part (ward_dist_exact_kernel "
                                           "runs at that rate); with 16 rows per pass the kernel is bound by vector-ALU issue, not by HBM"},
                          "note": "one workgroup per 64 live clusters streams their centroids once (LDS-DMA ring) and runs 16 in-order sums; "
-                                 "SURVEY.md 8d classifies the merge loop as HBM-bound, so the HBM fraction is reported as `frac`, the "
-                                 "vector-ALU fraction beside it; launches after the last merge of a 64-step chunk are empty",
+                                 "SURVEY.md 8d classifies the merge loop as HBM-bound, but with 16 rows per pass over the centroids the kernel "
+                                 "is bound by vector-ALU issue: `frac` is the vector-fp32 fraction (FMA-counted peak), `hbm` the HBM view; "
+                                 "launches after the last merge of a 64-step chunk are empty",
                          "total_ms_in_profile_pass": round(upd["ms"], 1),
                          "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
                                      "(the timed steps replay a hipGraph)"}
         conv_roof["total_ms_in_profile_pass"] = round(c128["ms"], 1)
         # `roofline` = the dominant kernel of THIS workload by GPU time in the profiling passes (at N=100 000 the batched Ward
-        # update, HBM bound; at configs[1]'s N=10 000 the 128x128 implicit-GEMM conv, MFMA bound); the other one sits beside it
+        # update, vector-ALU bound; at configs[1]'s N=10 000 the Cout >= 128 convolutions, MFMA bound); the other one sits beside it
         # (the conv time of the single-stream profiling pass is scaled to the timed region, where two forward passes overlap)
         conv_ms_timed = c128["ms"] * result.get("embed_ms", 0.0) / max(result.get("embed_ms_single_stream", 0.0), 1e-9)
         ward_dominates = ward_roof is not None and upd["ms"] > conv_ms_timed
@@ -336,12 +353,13 @@ def main():
             "metric": "images/sec (embed+Ward)" if not args.embed_only else "images/sec (embed only)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 bf16 "
+            "dtype": "bf16" if args.prec == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": ("%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 " + args.prec + " "
                                     "batch=%d -> 2048-d pooled E%s"
                                     % ("configs[3] (embed only)" if args.embed_only and n_total == 1000000
                                        else "embed only, custom size" if args.embed_only
                                        else "the metric's size (configs[2]'s N=100000) on %d GPU%s" % (world, "s" if world > 1 else "") if n_total == 100000
+                                       else "configs[4] (250 GB distance matrix on GPU0)" if n_total == 250000
                                        else "configs[1]" if n_total == 10000 and world == 1 else "custom size",
                                        n_total, n_local, args.batch,
                                        "" if args.embed_only else (" -> RCCL all-gather -> distance rows on all ranks, spans sent to GPU0" if world > 1 else "")))

@@ -32,7 +32,7 @@ def check_common(j):
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")  # "valu": the exact Ward update is bound by vector-ALU issue
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
     assert j["value"] > 0 and j["ms_per_step"] > 0
 
