@@ -354,8 +354,8 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if args.prec == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": ("%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 " + args.prec + " "
-                                    "batch=%d -> 2048-d pooled E%s"
+            "config": {"workload": (("%s: %d synthetic 224x224x3 images (structured, seed 20250217; %d on this rank), ResNet50-v1 " + args.prec +
+                                     " batch=%d -> 2048-d pooled E%s")
                                     % ("configs[3] (embed only)" if args.embed_only and n_total == 1000000
                                        else "embed only, custom size" if args.embed_only
                                        else "the metric's size (configs[2]'s N=100000) on %d GPU%s" % (world, "s" if world > 1 else "") if n_total == 100000

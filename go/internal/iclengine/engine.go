@@ -12,7 +12,9 @@ import "C"
 
 import (
 	"fmt"
+	"os"
 	"runtime"
+	"strconv"
 	"sync"
 	"unsafe"
 )
@@ -30,7 +32,11 @@ func Ctx() (unsafe.Pointer, error) {
 		// icl_last_error(NULL) reads a thread-local string: keep the failing call and the read on one OS thread
 		runtime.LockOSThread()
 		defer runtime.UnlockOSThread()
-		if rc := C.icl_create(0, &ctx); rc != C.ICL_OK {
+		dev := 0
+		if v, e := strconv.Atoi(os.Getenv("ICL_DEVICE")); e == nil && v >= 0 {
+			dev = v
+		}
+		if rc := C.icl_create(C.int(dev), &ctx); rc != C.ICL_OK {
 			err = fmt.Errorf("icl_create: %s", C.GoString(C.icl_last_error(nil)))
 		}
 	})

@@ -50,6 +50,7 @@ struct icl_ctx {
     int64_t *ward_rowoff = nullptr; // row offsets of the packed triangle for ranks that only compute distance rows (ward.hip)
     int64_t ward_rowoff_n = 0;
     void *file_batcher = nullptr; // icl_embed_file's coalescing queue (resnet.hip)
+    std::vector<const void *> lds_optin; // kernels whose > 64 KiB dynamic-LDS opt-in has been made on this context's device
     std::vector<int32_t> last_merges; // pairs
     std::vector<float> last_merge_vals; // Ward distance of each merged pair
 };
@@ -101,6 +102,16 @@ void icl_ward_free(icl_ctx *ctx);
 void icl_file_batcher_free(icl_ctx *ctx);
 
 static inline int64_t icl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (context, kernel): the attribute belongs to the device's copy of the code
+// object, and a group drives one context per GPU (process-wide `static bool` flags would opt in on the first device only).
+static inline void icl_lds_optin(icl_ctx *ctx, const void *fn, int bytes)
+{
+    for (const void *f : ctx->lds_optin)
+        if (f == fn) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    ctx->lds_optin.push_back(fn);
+}
 
 // splitmix64: the counter-based hash behind every synthetic input.
 __host__ __device__ static inline uint64_t icl_splitmix64(uint64_t x)

@@ -349,6 +349,7 @@ static int onnx_to_blob_impl(icl_ctx *ctx, const char *path, std::vector<char> &
         const onnx_node *b3 = c3 ? only(c3->out[0], "BatchNormalization") : nullptr;
         const onnx_node *add = b3 ? only(b3->out[0], "Add") : nullptr;
         if (!add) return walk_fail(i, "expected 1x1 -> BN -> Relu -> 3x3 -> BN -> Relu -> 1x1 -> BN -> Add");
+        if (add->in.size() != 2 || add->out.empty()) return walk_fail(i, "the block's Add must have two inputs and one output"); // (a hostile graph: a one-input Add would be indexed out of bounds below)
         const std::string &other = add->in[0] == b3->out[0] ? add->in[1] : add->in[0];
         if (has_ds) {
             const onnx_node *bd = ds->out.empty() ? nullptr : only(ds->out[0], "BatchNormalization");

@@ -322,6 +322,148 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
     conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (every bottleneck's c2: 16 of the 53 launches, 37 % of the conv time) with an
+// LDS-staged HALO tile.  conv_igemm_kernel stages, for each of the 9 taps, the 128 x 128-byte activation rows of that tap: the
+// same input pixel crosses L2 -> LDS nine times, and the K-heavy layers sit at the CU's L2 -> LDS delivery rate, not at the
+// MFMA rate.  Here a tile's 128 output pixels (linear in (b, oy, ox), as in conv_igemm_kernel) keep ONE image of
+// their input neighbourhood in LDS per 128-byte channel chunk -- the input rows oy-1 .. oy+1 of every output row touched, W + 2
+// pixels each (zero columns left and right) -- and all 9 taps read their A operand from it through per-lane pixel indices;
+// only the weights (BN x 128 B) are staged per k-step.  L2 -> LDS bytes per k-step: 16 KB + 30 KB / 9 instead of 32 KB
+// (Cin = 128, W = 28), LDS-DMA pieces per wave and k-step 4 + 1 instead of 8.
+//   k order: (channel chunk, kh, kw, channel in chunk) -- fixed per output element, so results do not depend on the batch.
+//   rows of a neighbouring IMAGE that fall into the halo are loaded like any other row; a lane whose output row is the first /
+//   last of its image reads the three "zero pixels" behind the image instead (the conv's zero padding).
+// ------------------------------------------------------------------------------------------------------------
+#define HALO_MAXP 12 /* halo pieces (8 pixels x 128 B) a wave fetches per channel chunk: tiles of up to 384 halo pixels */
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_args p, int npw /* halo pieces per wave */)
+{
+    typedef typename T::elem elem;
+    constexpr int NT = BN / 64;
+    constexpr int WI = BN / 32;          // weight pieces per wave per k-step
+    constexpr int WST = BN * CV_ROWB;    // one weight stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [halo image: 4*npw pieces][4 zero pixels][2 weight stages]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1;
+    const int tile = xcd_remap(blockIdx.x, p.gx * p.gy);
+    const int64_t m0 = (int64_t)(tile / p.gy) * CV_BM;
+    const int n0 = (tile % p.gy) * BN;
+    const elem *Xg = (const elem *)p.X;
+    const elem *Wg = (const elem *)p.Wt;
+    const int Wd = p.W, P = Wd + 2, H = p.H;
+    const int halo_bytes = 4 * npw * 1024;
+    const int ZP = halo_bytes >> 7; // pixel index of the first zero pixel
+    const int R0 = (int)((unsigned)m0 / (unsigned)Wd), Rlo = R0 - 1, totalR = p.B * H; // global rows (b * H + y); launch_conv checks M < 2^31
+    // ---- halo fill roles: piece = 8 consecutive halo pixels x 128 B; lane -> (pixel = lane >> 3, physical 16-byte slot = lane & 7)
+    const int prow = lane >> 3, ps = lane & 7;
+    int64_t hoff[HALO_MAXP]; // element offset of this lane's source chunk for channel chunk 0, or -1: the zero page
+#pragma unroll
+    for (int i = 0; i < HALO_MAXP; ++i) {
+        const int px = (wid * npw + i) * 8 + prow;
+        const int r = (int)((unsigned)px / (unsigned)P), c = px - r * P - 1, Rg = Rlo + r;
+        const bool ok = i < npw && (unsigned)Rg < (unsigned)totalR && (unsigned)c < (unsigned)Wd;
+        hoff[i] = ok ? ((int64_t)Rg * Wd + c) * p.Cin + lds_swz(px, ps) * T::KE : -1;
+    }
+    int64_t wbase[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = wid * (BN / 4) + i * 8 + prow;
+        wbase[i] = (int64_t)(n0 + row) * p.K + lds_swz(row, ps) * T::KE;
+    }
+    // ---- A-operand roles: the two output pixels of this lane (tile rows wm*64 + b*32 + fr) and, per filter row kh, the halo
+    // pixel under tap (kh, kw = 0); kw adds to the pixel index
+    const int fr = lane & 31, fh = lane >> 5;
+    int abase[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t m = m0 + wm * 64 + b * 32 + fr;
+        const bool valid = m < p.M;
+        const unsigned mm = valid ? (unsigned)m : (unsigned)m0;
+        const int R = (int)(mm / (unsigned)Wd), ox = (int)(mm - (unsigned)R * (unsigned)Wd);
+        const int oy = R - (int)((unsigned)R / (unsigned)H) * H;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy + kh - 1;
+            abase[b][kh] = (valid && (unsigned)iy < (unsigned)H) ? (R + kh - 1 - Rlo) * P + ox : ZP;
+        }
+    }
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const unsigned halo_dst = __builtin_amdgcn_readfirstlane(smem_base + wid * npw * 1024);
+    const unsigned w_dst = __builtin_amdgcn_readfirstlane(smem_base + halo_bytes + 512 + wid * (BN / 4) * CV_ROWB);
+    auto stage_halo = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < HALO_MAXP; ++i)
+            if (i < npw) glds16_asm(hoff[i] >= 0 ? (const void *)(Xg + hoff[i] + ci0) : p.zero, halo_dst + i * 1024);
+    };
+    auto stage_w = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) glds16_asm(Wg + wbase[i] + k0, w_dst + buf * WST + i * 8 * CV_ROWB);
+    };
+    if (tid < 32) reinterpret_cast<uint4 *>(smem + halo_bytes)[tid] = make_uint4(0, 0, 0, 0); // the zero pixels
+    const int nchunk = p.Cin / T::BK;
+    stage_halo(0);
+    stage_w(0, 0);
+    int ks = 0; // k-step counter: weight buffer parity
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++ks) {
+            const int kh = t / 3, kw = t % 3;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // this step's weights (and, at t == 0, the chunk's halo) are visible; the other weight buffer is free
+            if (t < 8) stage_w((kh * 3 + kw + 1) * p.Cin + c * T::BK, (ks + 1) & 1);
+            const unsigned char *wsm = smem + halo_bytes + 512 + (ks & 1) * WST;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uint4 wf[NT], xf[2];
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const int row = wn * (BN / 2) + a * 32 + fr;
+                    wf[a] = *reinterpret_cast<const uint4 *>(wsm + row * CV_ROWB + (lds_swz(row, 2 * s + fh) << 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int px = abase[b][kh] + kw;
+                    xf[b] = *reinterpret_cast<const uint4 *>(smem + px * CV_ROWB + (lds_swz(px, 2 * s + fh) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) T::mma(wf[a], xf[b], acc[a][b]);
+            }
+            if (t == 8 && c + 1 < nchunk) {
+                __syncthreads(); // every wave has read the last tap of this chunk's halo
+                stage_halo((c + 1) * T::BK);
+                stage_w((c + 1) * T::BK, (ks + 1) & 1);
+            }
+        }
+    }
+    __syncthreads(); // the epilogue reuses the LDS
+    conv_epilogue<T, BN>(p, smem, acc, m0, n0, tid, wm, wn, fr, fh, conv_resid<T, BN>());
+}
+
+// halo pieces per wave for an image width (0: the shape does not fit the halo kernel)
+static int conv3x3_halo_npw(int W)
+{
+    const int rows = (W - 1 + CV_BM - 1) / W + 1 + 2; // image rows a run of 128 pixels can touch, plus one above and below
+    const int pieces = (rows * (W + 2) + 7) / 8;
+    const int npw = (pieces + 3) / 4;
+    return npw <= HALO_MAXP ? npw : 0;
+}
+template <int BN>
+static size_t conv3x3_halo_lds(int npw)
+{
+    const size_t body = (size_t)4 * npw * 1024 + 512 + (size_t)2 * BN * CV_ROWB, ep = (size_t)64 * (BN + 4) * 4;
+    return body > ep ? body : ep;
+}
+
 template <int BN>
 static constexpr size_t conv_lds_bytes(int nstages = 2)
 {
@@ -863,12 +1005,7 @@ static int ensure_ws(icl_ctx *ctx, int batch, int prec, int lanes)
 template <typename T, int BN, bool DUAL, int NST, bool EARLY = false>
 static void launch_conv_variant(icl_ctx *ctx, conv_args &a, int nst_lds)
 {
-    static bool attr_done = false; // one flag per instantiation: opt in to > 64 KiB of dynamic LDS
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<T, BN, DUAL, NST, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)conv_lds_bytes<BN>(NST));
-        attr_done = true;
-    }
+    icl_lds_optin(ctx, (const void *)conv_igemm_kernel<T, BN, DUAL, NST, EARLY>, (int)conv_lds_bytes<BN>(NST)); // > 64 KiB of dynamic LDS
     a.gy = a.Cout / BN;
     hipLaunchKernelGGL((conv_igemm_kernel<T, BN, DUAL, NST, EARLY>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv_lds_bytes<BN>(nst_lds), ctx->cur_stream ? ctx->cur_stream : ctx->stream,
                        a);
@@ -884,12 +1021,30 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
 {
     a.gx = (int)icl_ceil_div(a.M, CV_BM);
     const int nk = a.K / T::BK;
-    static const bool early = [] {
+    static const int mode = [] { // ICL_CONV_MODE (A/B measurements): 0 = plain two-stage loop, 2 = no halo kernel for the 3x3 layers
         const char *e = getenv("ICL_CONV_MODE");
-        return !(e && atoi(e) == 0);
+        return e ? atoi(e) : 1;
     }();
+    const bool early = mode != 0;
     const bool wide = a.Cout % 128 == 0;
     icl_prof_scope ps(ctx, wide ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
+    if (mode == 1 && !a.X2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W) {
+        const int npw = conv3x3_halo_npw(a.W); // every 3x3 layer of ResNet50 (W = 56, 28, 14, 7) fits
+        if (npw) {
+            hipStream_t strm = ctx->cur_stream ? ctx->cur_stream : ctx->stream;
+            if (wide) {
+                a.gy = a.Cout / 128;
+                icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, 128>, (int)conv3x3_halo_lds<128>(HALO_MAXP));
+                hipLaunchKernelGGL((conv3x3_halo_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<128>(npw), strm, a, npw);
+            } else {
+                a.gy = a.Cout / 64;
+                icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, 64>, (int)conv3x3_halo_lds<64>(HALO_MAXP));
+                hipLaunchKernelGGL((conv3x3_halo_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<64>(npw), strm, a, npw);
+            }
+            ICL_HIP(ctx, hipGetLastError());
+            return ICL_OK;
+        }
+    }
     const int nst = nk > 1 ? 2 : 1; // single-k-step layers need one stage only -> more workgroups per CU
     if (a.X2) {
         if (early) launch_conv_variant<T, 128, true, 2, true>(ctx, a, 2);
@@ -1049,11 +1204,7 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     elem *x = (elem *)m->buf[lane][0], *t1 = (elem *)m->buf[lane][1], *t2 = (elem *)m->buf[lane][2], *ds = (elem *)m->buf[lane][3],
          *y = (elem *)m->buf[lane][4];
     {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)stem_conv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_lds_bytes<T>());
-            attr_done = true;
-        }
+        icl_lds_optin(ctx, (const void *)stem_conv_kernel<T>, (int)stem_lds_bytes<T>());
         conv_args a;
         const conv_layer &L = m->conv[0];
         a.X = nullptr; a.Wt = L.w[prec]; a.Y = y; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
@@ -1477,6 +1628,7 @@ struct icl_file_batcher {
     std::condition_variable cv;
     std::vector<icl_file_req *> pending;
     bool leader = false;
+    int inflight = 0; // callers inside icl_embed_file (decoding, queued or being served): a leader stops waiting once all of them are queued
     int prec = ICL_PREC_FP32;
     int window_us = 2000;
     int max_batch = 256;
@@ -1522,56 +1674,96 @@ extern "C" int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *o
     if (!ctx || !path || !out) return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_file: bad argument");
     if (head != ICL_HEAD_POOLED && head != ICL_HEAD_DENSE0) return icl_fail(ctx, ICL_ERR_ARG, "head must be 2048 or 1000");
     return no_throw(ctx, "icl_embed_file", [&]() -> int {
+        icl_file_batcher *b = file_batcher(ctx);
+        struct inflight_guard { // counts this caller in from before it queues until it leaves, whatever the exit
+            icl_file_batcher *b;
+            explicit inflight_guard(icl_file_batcher *bb) : b(bb)
+            {
+                std::lock_guard<std::mutex> g(b->m);
+                ++b->inflight;
+            }
+            ~inflight_guard()
+            {
+                std::lock_guard<std::mutex> g(b->m);
+                --b->inflight;
+                b->cv.notify_all();
+            }
+        };
+        inflight_guard ig(b);
         std::vector<uint8_t> rgb, img((size_t)ICL_IMG_BYTES);
         int w = 0, h = 0;
         ICL_TRY(read_image(ctx, path, rgb, w, h)); // decode + resize run on the caller's thread, in parallel with other callers
         resize_bilinear_u8(rgb.data(), w, h, img.data(), ICL_IMG_W, ICL_IMG_H);
-        icl_file_batcher *b = file_batcher(ctx);
         icl_file_req me;
         me.img = img.data();
         me.out = out;
         me.head = head;
         std::unique_lock<std::mutex> lk(b->m);
         b->pending.push_back(&me);
-        if ((int)b->pending.size() >= b->max_batch) b->cv.notify_all(); // a waiting leader need not sit out its window
+        b->cv.notify_all(); // a waiting leader re-checks whether its batch is full / everybody who entered is queued
         while (!me.done) {
             if (b->leader) { // someone else is collecting or running a batch: wait for my row (or for the leadership)
                 b->cv.wait(lk);
                 continue;
             }
             b->leader = true;
-            if (b->window_us > 0 && (int)b->pending.size() < b->max_batch)
-                b->cv.wait_for(lk, std::chrono::microseconds(b->window_us), [&] { return (int)b->pending.size() >= b->max_batch; });
+            // From here on this thread owes every request it takes a result: whatever goes wrong (bad_alloc in the slab copies,
+            // an exception out of the forward pass) each taken request is completed with an error, the leadership is given up and
+            // everybody is woken -- a leader that left with `leader` still set would block every later caller for good.
             std::vector<icl_file_req *> take;
-            take.swap(b->pending);
-            if ((int)take.size() > b->max_batch) {
-                b->pending.assign(take.begin() + b->max_batch, take.end());
-                take.resize((size_t)b->max_batch);
-            }
-            const int prec = b->prec;
-            lk.unlock();
-            for (int hd : {ICL_HEAD_POOLED, ICL_HEAD_DENSE0}) { // one forward pass per requested head
-                std::vector<icl_file_req *> grp;
+            auto finish = [&](int rc, const char *why) { // lock held
                 for (icl_file_req *r : take)
-                    if (r->head == hd) grp.push_back(r);
-                if (grp.empty()) continue;
-                std::vector<uint8_t> slab(grp.size() * (size_t)ICL_IMG_BYTES);
-                std::vector<float> res(grp.size() * (size_t)hd);
-                for (size_t i = 0; i < grp.size(); ++i) memcpy(&slab[i * (size_t)ICL_IMG_BYTES], grp[i]->img, (size_t)ICL_IMG_BYTES);
-                const int rc = icl_embed_u8(ctx, slab.data(), (int64_t)grp.size(), hd, prec, res.data());
-                const std::string err = rc ? ctx->err : std::string();
-                for (size_t i = 0; i < grp.size(); ++i) {
-                    grp[i]->rc = rc;
-                    grp[i]->err = err;
-                    if (rc == ICL_OK) memcpy(grp[i]->out, &res[i * (size_t)hd], (size_t)hd * 4);
+                    if (!r->done) {
+                        if (rc != ICL_OK) {
+                            r->rc = rc;
+                            try {
+                                r->err = why;
+                            } catch (...) {
+                            }
+                        }
+                        r->done = true;
+                    }
+                b->leader = false;
+                b->cv.notify_all(); // followers pick up their rows; one of the still-pending callers becomes the next leader
+            };
+            try {
+                // the window only matters while other callers are still decoding: a lone caller (or the last of a burst) runs at once
+                if (b->window_us > 0)
+                    b->cv.wait_for(lk, std::chrono::microseconds(b->window_us),
+                                   [&] { return (int)b->pending.size() >= b->max_batch || (int)b->pending.size() >= b->inflight; });
+                take.swap(b->pending);
+                if ((int)take.size() > b->max_batch) {
+                    b->pending.assign(take.begin() + b->max_batch, take.end());
+                    take.resize((size_t)b->max_batch);
                 }
+                const int prec = b->prec;
+                lk.unlock();
+                if (getenv("ICL_TEST_LEADER_THROW")) throw std::bad_alloc(); // fault injection for tests/test_pipeline_gpu.py
+                for (int hd : {ICL_HEAD_POOLED, ICL_HEAD_DENSE0}) { // one forward pass per requested head
+                    std::vector<icl_file_req *> grp;
+                    for (icl_file_req *r : take)
+                        if (r->head == hd) grp.push_back(r);
+                    if (grp.empty()) continue;
+                    std::vector<uint8_t> slab(grp.size() * (size_t)ICL_IMG_BYTES);
+                    std::vector<float> res(grp.size() * (size_t)hd);
+                    for (size_t i = 0; i < grp.size(); ++i) memcpy(&slab[i * (size_t)ICL_IMG_BYTES], grp[i]->img, (size_t)ICL_IMG_BYTES);
+                    const int rc = icl_embed_u8(ctx, slab.data(), (int64_t)grp.size(), hd, prec, res.data());
+                    const std::string err = rc ? ctx->err : std::string();
+                    for (size_t i = 0; i < grp.size(); ++i) {
+                        grp[i]->rc = rc;
+                        grp[i]->err = err;
+                        if (rc == ICL_OK) memcpy(grp[i]->out, &res[i * (size_t)hd], (size_t)hd * 4);
+                    }
+                }
+                lk.lock();
+                b->batches += 1;
+                b->images += (int64_t)take.size();
+                finish(ICL_OK, "");
+            } catch (...) {
+                if (!lk.owns_lock()) lk.lock();
+                if (take.empty()) take.swap(b->pending); // failed before the batch was cut: nobody may be left waiting for this leader
+                finish(ICL_ERR_NOMEM, "icl_embed_file: the batch leader ran out of memory");
             }
-            lk.lock();
-            b->batches += 1;
-            b->images += (int64_t)take.size();
-            for (icl_file_req *r : take) r->done = true;
-            b->leader = false;
-            b->cv.notify_all(); // followers pick up their rows; one of the still-pending callers becomes the next leader
         }
         if (me.rc != ICL_OK) return icl_fail(ctx, me.rc, "%s", me.err.c_str());
         return ICL_OK;

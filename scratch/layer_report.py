@@ -18,7 +18,7 @@ for s in range(4):
         # block 0: the downsample conv is fused into c3 (dual-operand K axis = mid + cin)
         layers.append(('s%d.b%d.c3'%(s+1,bl),mid + (cin if bl==0 else 0),cout,1,ho))
         cin=cout;h=ho
-convs=[e for e in batch if 'conv_igemm' in e[2]]
+convs=[e for e in batch if 'conv_igemm' in e[2] or 'conv3x3_halo' in e[2]]
 tot=0;totf=0;agg={}
 for (s,e,n),(name,ci,co,k,ho) in zip(convs,layers):
     M=256*ho*ho; K=ci*k*k; fl=2*M*co*K; us=(e-s)/1e3
@@ -31,5 +31,5 @@ for key,(us,fl,c) in sorted(agg.items(), key=lambda kv:-kv[1][0]):
     byt=(M*ci*(1 if k==1 else 1)+M*co*(2 if (k==1 and co>=256 and ci<co) else 1))*2*c  # rough: in + out (+res)
     print("cin=%4d cout=%4d k=%d ho=%3d x%d  M=%7d K=%5d  %8.1f us  %6.1f TF/s  ~%5.2f TB/s  share %4.1f%%"%(ci,co,k,ho,c,M,ci*k*k,us,fl/us/1e6,byt/us/1e6,100*us/tot))
 print('total conv us',round(tot,1),'TF/s',round(totf/tot/1e6,1))
-print('other', [ (e[2][:30], round((e[1]-e[0])/1e3,1)) for e in batch if 'conv_igemm' not in e[2]])
+print('other', [ (e[2][:30], round((e[1]-e[0])/1e3,1)) for e in batch if 'conv_igemm' not in e[2] and 'conv3x3_halo' not in e[2]])
 print('batch span us', (batch[-1][1]-batch[0][0])/1e3)

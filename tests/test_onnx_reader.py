@@ -184,4 +184,17 @@ def test_reader_rejects_graphs_that_are_not_resnet50(blob, tmp_path):
     open(bad, "wb").write(m3.SerializeToString())
     with pytest.raises(_lib.ICLError):
         _lib.onnx_to_blob(bad)
+    # (c) a hostile graph whose block Add has ONE input (the bn3 output): rejected, not indexed out of bounds
+    m4 = P.ModelProto()
+    m4.CopyFrom(model)
+    victim = [n for n in m4.graph.node if n.op_type == "Add"][1]
+    bn3_out = victim.input[0] if victim.input[1] in relus or victim.input[1] == "x" else victim.input[1]
+    bns = {n.output[0] for n in m4.graph.node if n.op_type == "BatchNormalization"}
+    keep = [t for t in victim.input if t in bns][:1] or [bn3_out]
+    del victim.input[:]
+    victim.input.extend(keep)
+    bad = str(tmp_path / "add1.onnx")
+    open(bad, "wb").write(m4.SerializeToString())
+    with pytest.raises(_lib.ICLError, match="not a ResNet50-v1 graph"):
+        _lib.onnx_to_blob(bad)
     assert relus

@@ -121,3 +121,50 @@ def test_get_image_embedding_from_64_goroutine_like_threads_is_coalesced(ctx, L,
     emb, err = EM.GetImageEmbedding(app, str(tmp_path / "missing.jpg"))
     assert emb is None and "failed to read image" in err
     ctx.set_file_options(L.PREC_FP32, 2000, 256)
+
+
+def test_batch_leader_failure_releases_every_caller(ctx, L, tmp_path):
+    """the coalescing leader of icl_embed_file must not strand its followers.  With a failure injected into the
+    leader's batch section (bad_alloc right after it has taken the queued requests) every one of 16 concurrent callers returns
+    an error -- nobody hangs -- and the next calls on the same context work again, a lone caller without sitting out a long window."""
+    import os
+    import time
+
+    rng = np.random.default_rng(6)
+    paths = []
+    for i in range(16):
+        arr = rng.integers(0, 256, (150, 200, 3), dtype=np.uint8)
+        p = tmp_path / ("f_%d.ppm" % i)
+        with open(p, "wb") as f:
+            f.write(b"P6\n200 150\n255\n" + arr.tobytes())
+        paths.append(str(p))
+    ctx.set_file_options(L.PREC_FP32, 20000, 64)
+    res = [None] * 16
+    gate = threading.Barrier(16)
+
+    def worker(i):
+        gate.wait()
+        try:
+            ctx.embed_file(paths[i], L.HEAD_DENSE0)
+            res[i] = "ok"
+        except L.ICLError as e:
+            res[i] = e.code
+
+    os.environ["ICL_TEST_LEADER_THROW"] = "1"
+    try:
+        th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(16)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert not any(t.is_alive() for t in th), "a caller is still blocked behind a failed leader"
+    finally:
+        del os.environ["ICL_TEST_LEADER_THROW"]
+    assert all(r == L.ICL_ERR_NOMEM for r in res), res
+    want = ctx.embed_u8(np.stack([L.load_image_224(p) for p in paths[:2]]), L.HEAD_DENSE0, L.PREC_FP32)
+    ctx.set_file_options(L.PREC_FP32, 500000, 256)  # a lone caller must not wait for this half-second window: nobody else is inside
+    t0 = time.perf_counter()
+    assert np.array_equal(ctx.embed_file(paths[0], L.HEAD_DENSE0), want[0])
+    assert time.perf_counter() - t0 < 0.4
+    assert np.array_equal(ctx.embed_file(paths[1], L.HEAD_DENSE0), want[1])
+    ctx.set_file_options(L.PREC_FP32, 2000, 256)
