@@ -72,6 +72,7 @@ SYMBOLS = [
     ("icl_group_load_synthetic", _int, [_vp, C.c_uint64]),
     ("icl_group_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_group_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_group_embed_cluster", _int, [_vp, _vp, _i64, _int, _i32, _i32, _int, _vp, _vp, _vp, _pi32]),
     ("icl_ward_rows_partition", _int, [_i64, _i32, _i32, _pi64, _pi64]),
     ("icl_ward_span", _int, [_i64, _i64, _pi64, _pi64]),
     ("icl_ward_distance_rows_dev", _int, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
@@ -446,6 +447,19 @@ class Group:
         nc = _i32()
         self._check(self.L.icl_group_cluster(self.g, E.ctypes.data, n, d, min_size, max_size, update, cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
+
+    def embed_cluster(self, imgs, min_size, max_size, prec=PREC_BF16, update=UPDATE_EXACT, want_E=True):
+        """workflow.go:84-94 in one call: embed (2048-d pooled) on all GPUs, E assembled on the devices, clustered on GPU 0.
+        -> (E or None, cluster_id, member_rank, n_clusters)"""
+        imgs = np.ascontiguousarray(imgs, np.uint8).reshape(-1, IMG_BYTES)
+        n = imgs.shape[0]
+        E = np.empty((n, HEAD_POOLED), np.float32) if want_E else None
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        self._check(self.L.icl_group_embed_cluster(self.g, imgs.ctypes.data, n, prec, min_size, max_size, update,
+                                                   E.ctypes.data if want_E else None, cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
+        return E, cid[:n], rank[:n], nc.value
 
 
 def calc_optimal_clusters(total, min_size, max_size):

@@ -2,10 +2,12 @@
 // 8e rows 1-2).  A Go service is one process: internal/workflow calls GetImageEmbedding / PerformClusteringWithConstraints
 // (workflow.go:161,89) and cannot start one process per GPU, so the group drives N contexts from N host threads:
 //   * embed: images shard by contiguous index ranges (no exchange: every GPU holds the weights);
-//   * cluster: every GPU gets E, computes the distance rows of an area-balanced run of 128-row tile rows
-//     (icl_ward_rows_partition) and its span is copied device-to-device into GPU 0's packed triangle (hipMemcpyPeerAsync:
-//     xGMI when the devices are peers); GPU 0 runs the exact merge loop.  Results are bit-identical to one GPU: the same
-//     kernel computes every row, only where it runs changes.
+//   * cluster: every GPU holds E (uploaded once to GPU 0 and passed on by peer copies, or -- icl_group_embed_cluster --
+//     assembled on the GPUs from the embedding shards without touching the host), computes the distance rows of an
+//     area-balanced run of 128-row tile rows (icl_ward_rows_partition) and its span is copied device-to-device into staging
+//     memory of GPU 0 (hipMemcpyPeerAsync: xGMI when the devices are peers); GPU 0 lays the spans out into its distance matrix
+//     and runs the exact merge loop.  Results are bit-identical to one GPU: the same kernel computes every row, only where it
+//     runs changes.
 // Entries of `devices` may repeat (a test on a 1-GPU box builds a group of two contexts on device 0: the same code path,
 // the peer copy degenerates to a device-to-device copy).
 // The process-per-GPU path of bench.py uses the same building blocks (icl_ward_distance_rows_dev / icl_ward_span_ptr /
@@ -125,6 +127,51 @@ extern "C" int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t 
     });
 }
 
+// The distance build + merge loop of a group on embeddings that are ALREADY resident on every GPU (dE[i]: n x d on GPU i):
+// every GPU computes the distance rows of its area-balanced run of 128-row tile rows (GPU 0 too, at the same time); the spans
+// of GPUs 1.. are copied device-to-device into staging buffers of GPU 0 that were reserved up front, each by its own host
+// thread on a stream of its own -- no lock of GPU 0's context is taken on the way, so the N-1 spans arrive concurrently (one
+// xGMI link each) while GPU 0 computes; GPU 0 then lays the spans out into its matrix and runs the exact merge loop.
+static int group_cluster_resident(icl_group *g, const std::vector<float *> &dE, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
+                                  int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    const int parts = (int)g->ctx.size();
+    icl_ctx *c0 = g->ctx[0];
+    int rc = icl_ward_prepare(c0, n, d);
+    if (rc != ICL_OK) return group_fail(g, rc, icl_last_error(c0));
+    std::vector<float *> dSpan((size_t)parts, nullptr), stage((size_t)parts, nullptr);
+    std::vector<int64_t> lo((size_t)parts, 0), hi((size_t)parts, 0), cnt((size_t)parts, 0);
+    for (int i = 0; i < parts && rc == ICL_OK; ++i) {
+        rc = icl_ward_rows_partition(n, parts, i, &lo[(size_t)i], &hi[(size_t)i]);
+        void *p = nullptr;
+        if (rc == ICL_OK && hi[(size_t)i] > lo[(size_t)i]) rc = icl_ward_span_ptr(c0, lo[(size_t)i], hi[(size_t)i], &p, &cnt[(size_t)i]); // reserves the staging buffer on GPU 0
+        stage[(size_t)i] = (float *)p;
+    }
+    if (rc != ICL_OK) return group_fail(g, rc, icl_last_error(c0));
+    rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+        if (hi[(size_t)i] == lo[(size_t)i]) return ICL_OK;
+        if (i == 0) return icl_ward_distance_rows_dev(c, dE[0], n, d, lo[0], hi[0], stage[0]);
+        void *p = nullptr;
+        ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(cnt[(size_t)i] * 4, 16), &p));
+        dSpan[(size_t)i] = (float *)p;
+        ICL_TRY(icl_ward_distance_rows_dev(c, dE[(size_t)i], n, d, lo[(size_t)i], hi[(size_t)i], dSpan[(size_t)i]));
+        icl_device_guard dg(c->device);
+        hipStream_t cs = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(stage[(size_t)i], c0->device, dSpan[(size_t)i], c->device, (size_t)cnt[(size_t)i] * 4, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        if (cs) (void)hipStreamDestroy(cs);
+        return e == hipSuccess ? (int)ICL_OK : icl_fail(c, ICL_ERR_HIP, "span of rows [%lld, %lld) -> GPU %d failed: %s", (long long)lo[(size_t)i], (long long)hi[(size_t)i], c0->device, hipGetErrorString(e));
+    });
+    if (rc == ICL_OK) {
+        rc = icl_cluster_prefilled_dev(c0, dE[0], n, d, min_size, max_size, update, 0, 0, cluster_id, member_rank, n_clusters);
+        if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
+    }
+    for (int i = 0; i < parts; ++i)
+        if (dSpan[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dSpan[(size_t)i]);
+    return rc;
+}
+
 extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                  int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
@@ -137,37 +184,113 @@ extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_
         const int rc = icl_cluster(c0, E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
         return rc == ICL_OK ? rc : group_fail(g, rc, icl_last_error(c0));
     }
-    int rc = icl_ward_prepare(c0, n, d);
-    if (rc != ICL_OK) return group_fail(g, rc, icl_last_error(c0));
-    std::vector<float *> dE((size_t)parts, nullptr), dSpan((size_t)parts, nullptr);
+    // E crosses PCIe ONCE (into GPU 0); the other GPUs get it by peer copies (xGMI when the devices are peers)
+    std::vector<float *> dE((size_t)parts, nullptr);
     auto cleanup = [&] {
-        for (int i = 0; i < parts; ++i) {
+        for (int i = 0; i < parts; ++i)
             if (dE[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dE[(size_t)i]);
-            if (dSpan[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dSpan[(size_t)i]);
-        }
     };
-    rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
-        int64_t lo = 0, hi = 0, off = 0, cnt = 0;
-        ICL_TRY(icl_ward_rows_partition(n, parts, i, &lo, &hi));
-        ICL_TRY(icl_ward_span(lo, hi, &off, &cnt));
+    const int64_t ebytes = n * (int64_t)d * 4;
+    int rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
         void *p = nullptr;
-        ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(n * d * 4, 16), &p));
+        ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(ebytes, 16), &p));
         dE[(size_t)i] = (float *)p;
-        ICL_TRY(icl_memcpy_h2d(c, p, E, n * (int64_t)d * 4));
-        if (hi == lo) return ICL_OK;
-        if (i == 0) { // GPU 0 writes its own rows straight into its triangle
-            void *dst = nullptr;
-            int64_t c2 = 0;
-            ICL_TRY(icl_ward_span_ptr(c, lo, hi, &dst, &c2));
-            return icl_ward_distance_rows_dev(c, dE[0], n, d, lo, hi, (float *)dst);
-        }
-        ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(cnt * 4, 16), &p));
-        dSpan[(size_t)i] = (float *)p;
-        ICL_TRY(icl_ward_distance_rows_dev(c, dE[(size_t)i], n, d, lo, hi, dSpan[(size_t)i]));
-        return icl_ward_deposit_dev(c0, lo, hi, dSpan[(size_t)i]); // device i -> GPU 0's triangle (peer copy over xGMI)
+        return i == 0 ? icl_memcpy_h2d(c, p, E, ebytes) : (int)ICL_OK;
     });
+    if (rc == ICL_OK)
+        rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+            if (i == 0) return ICL_OK;
+            icl_device_guard dg(c->device);
+            if (hipMemcpyPeer(dE[(size_t)i], c->device, dE[0], c0->device, (size_t)ebytes) != hipSuccess)
+                return icl_fail(c, ICL_ERR_HIP, "peer copy of E from GPU %d failed: %s", c0->device, hipGetErrorString(hipGetLastError()));
+            return ICL_OK;
+        });
+    if (rc == ICL_OK) rc = group_cluster_resident(g, dE, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+    cleanup();
+    return rc;
+}
+
+// workflow.go:84-94 in one call: createEmbeddings (the per-image GetImageEmbedding fan-out, :149-185) followed by
+// PerformClusteringWithConstraints (:89) -- with the embeddings staying ON the GPUs in between.  Images shard by contiguous
+// index ranges; every GPU embeds its shard straight into its own full-size E buffer; the shards are exchanged by peer copies
+// (an all-gather written as N x (N-1) point-to-point copies: xGMI is a mesh of links, every byte crosses exactly one);
+// then the distance rows / merge loop of group_cluster_resident.  Nothing crosses PCIe between embed and cluster; E_out
+// (host, n x 2048, may be NULL) receives the pooled embeddings afterwards.  Results are bit-identical to
+// icl_embed_u8 + icl_cluster on one GPU.
+extern "C" int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update,
+                                       float *E_out, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    if (!g || n < 0 || !n_clusters || (n && (!hwc_rgb || !cluster_id || !member_rank))) return group_fail(g, ICL_ERR_ARG, "icl_group_embed_cluster: bad argument");
+    const int parts = (int)g->ctx.size();
+    const int32_t d = ICL_HEAD_POOLED;
+    icl_ctx *c0 = g->ctx[0];
+    int64_t kk = 0;
+    if (n == 0) {
+        *n_clusters = 0;
+        return ICL_OK;
+    }
+    const bool resident = parts > 1 && update == ICL_UPDATE_EXACT && n >= 2 * 128 * parts && icl_calc_optimal_clusters(n, min_size, max_size, &kk) == ICL_OK;
+    std::vector<float *> dE((size_t)parts, nullptr);
+    auto cleanup = [&] {
+        for (int i = 0; i < parts; ++i)
+            if (dE[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dE[(size_t)i]);
+    };
+    const int64_t ebytes = n * (int64_t)d * 4;
+    // 1. every GPU embeds its shard into its own n x 2048 buffer (only GPU 0 needs the full buffer when the rest is not dealt out)
+    int rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+        int64_t lo, hi;
+        shard_range(n, parts, i, lo, hi);
+        void *p = nullptr;
+        if (i == 0 || resident) {
+            ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(ebytes, 16), &p));
+            dE[(size_t)i] = (float *)p;
+        }
+        if (hi == lo) return ICL_OK;
+        void *di = nullptr;
+        ICL_TRY(icl_dev_malloc(c, (hi - lo) * (int64_t)ICL_IMG_BYTES, &di));
+        int r2 = icl_memcpy_h2d(c, di, hwc_rgb + lo * (int64_t)ICL_IMG_BYTES, (hi - lo) * (int64_t)ICL_IMG_BYTES);
+        float *dst = dE[(size_t)i] ? dE[(size_t)i] + lo * d : nullptr;
+        void *tmp = nullptr;
+        if (r2 == ICL_OK && !dst) { // not dealt out: the shard goes to a buffer of its own and is copied to GPU 0 below
+            r2 = icl_dev_malloc(c, (hi - lo) * (int64_t)d * 4, &tmp);
+            dst = (float *)tmp;
+        }
+        if (r2 == ICL_OK) r2 = icl_embed_u8_dev(c, (const uint8_t *)di, hi - lo, d, prec, dst);
+        if (r2 == ICL_OK && tmp) {
+            icl_device_guard dg(c->device);
+            if (hipMemcpyPeer(dE[0] + lo * d, c0->device, tmp, c->device, (size_t)((hi - lo) * (int64_t)d * 4)) != hipSuccess)
+                r2 = icl_fail(c, ICL_ERR_HIP, "peer copy of an embedding shard to GPU %d failed", c0->device);
+        }
+        (void)icl_dev_free(c, di);
+        if (tmp) (void)icl_dev_free(c, tmp);
+        return r2;
+    });
+    // 2. the all-gather of E as point-to-point copies: GPU i sends its shard to every other GPU (all pairs concurrently)
+    if (rc == ICL_OK && resident)
+        rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+            int64_t lo, hi;
+            shard_range(n, parts, i, lo, hi);
+            if (hi == lo) return ICL_OK;
+            icl_device_guard dg(c->device);
+            hipStream_t cs = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            for (int j = 0; j < parts && e == hipSuccess; ++j)
+                if (j != i)
+                    e = hipMemcpyPeerAsync(dE[(size_t)j] + lo * d, g->ctx[(size_t)j]->device, dE[(size_t)i] + lo * d, c->device, (size_t)((hi - lo) * (int64_t)d * 4), cs);
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            if (cs) (void)hipStreamDestroy(cs);
+            return e == hipSuccess ? (int)ICL_OK : icl_fail(c, ICL_ERR_HIP, "all-gather of E (peer copies from GPU %d) failed: %s", c->device, hipGetErrorString(e));
+        });
+    // 3. cluster on the resident embeddings
     if (rc == ICL_OK) {
-        rc = icl_cluster_prefilled_dev(c0, dE[0], n, d, min_size, max_size, update, 0, 0, cluster_id, member_rank, n_clusters);
+        if (resident) rc = group_cluster_resident(g, dE, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+        else {
+            rc = icl_cluster_dev(c0, dE[0], n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+            if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
+        }
+    }
+    if (rc == ICL_OK && E_out) {
+        rc = icl_memcpy_d2h(c0, E_out, dE[0], ebytes);
         if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
     }
     cleanup();

@@ -336,14 +336,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const conv_args p)
 //   last of its image reads the three "zero pixels" behind the image instead (the conv's zero padding).
 // ------------------------------------------------------------------------------------------------------------
 #define HALO_MAXP 12 /* halo pieces (8 pixels x 128 B) a wave fetches per channel chunk: tiles of up to 384 halo pixels */
-template <typename T, int BN>
+// HALO_WS weight stages: 3 (two k-steps of weights in flight) where two workgroups still fit a CU's 160 KB of LDS, else 2 --
+// measured (W = 28, Cin = 128: 81 KB with three stages): one workgroup per CU costs 37 % on that layer, the third stage gains 0-2 % elsewhere
+template <typename T, int BN, int HALO_WS>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_args p, int npw /* halo pieces per wave */)
 {
     typedef typename T::elem elem;
     constexpr int NT = BN / 64;
     constexpr int WI = BN / 32;          // weight pieces per wave per k-step
     constexpr int WST = BN * CV_ROWB;    // one weight stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [halo image: 4*npw pieces][4 zero pixels][2 weight stages]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // [halo image: 4*npw pieces][4 zero pixels][HALO_WS weight stages]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 1, wn = wid >> 1;
     const int tile = xcd_remap(blockIdx.x, p.gx * p.gy);
@@ -409,17 +411,27 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_args p, in
     };
     if (tid < 32) reinterpret_cast<uint4 *>(smem + halo_bytes)[tid] = make_uint4(0, 0, 0, 0); // the zero pixels
     const int nchunk = p.Cin / T::BK;
+    const int nk = 9 * nchunk;
+    auto kof = [&](int q) { // k offset of k-step q = (chunk q / 9, tap q % 9) in the [Cout][kh][kw][Cin] weights
+        const int c = q / 9, t = q - 9 * c;
+        return t * p.Cin + c * T::BK;
+    };
+    constexpr int AHEAD = HALO_WS - 1; // k-steps of weights in flight beyond the current one
     stage_halo(0);
-    stage_w(0, 0);
-    int ks = 0; // k-step counter: weight buffer parity
+    stage_w(kof(0), 0);
+    if (AHEAD > 1 && nk > 1) stage_w(kof(1), 1);
+    int ks = 0; // k-step counter
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++ks) {
             const int kh = t / 3, kw = t % 3;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads(); // this step's weights (and, at t == 0, the chunk's halo) are visible; the other weight buffer is free
-            if (t < 8) stage_w((kh * 3 + kw + 1) * p.Cin + c * T::BK, (ks + 1) & 1);
-            const unsigned char *wsm = smem + halo_bytes + 512 + (ks & 1) * WST;
+            // this step's weights have landed once only the next step's are outstanding; at a chunk's first tap the halo (issued
+            // after them) must be in as well
+            if (AHEAD < 2 || t == 0 || ks + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WI) : "memory");
+            __syncthreads(); // ... and are visible to every wave; the weight buffer read at step ks-1 is free
+            if (ks + AHEAD < nk) stage_w(kof(ks + AHEAD), (ks + AHEAD) % HALO_WS);
+            const unsigned char *wsm = smem + halo_bytes + 512 + (ks % HALO_WS) * WST;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint4 wf[NT], xf[2];
@@ -441,7 +453,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const conv_args p, in
             if (t == 8 && c + 1 < nchunk) {
                 __syncthreads(); // every wave has read the last tap of this chunk's halo
                 stage_halo((c + 1) * T::BK);
-                stage_w((c + 1) * T::BK, (ks + 1) & 1);
             }
         }
     }
@@ -458,10 +469,23 @@ static int conv3x3_halo_npw(int W)
     return npw <= HALO_MAXP ? npw : 0;
 }
 template <int BN>
-static size_t conv3x3_halo_lds(int npw)
+static size_t conv3x3_halo_lds(int npw, int ws)
 {
-    const size_t body = (size_t)4 * npw * 1024 + 512 + (size_t)2 * BN * CV_ROWB, ep = (size_t)64 * (BN + 4) * 4;
+    const size_t body = (size_t)4 * npw * 1024 + 512 + (size_t)ws * BN * CV_ROWB, ep = (size_t)64 * (BN + 4) * 4;
     return body > ep ? body : ep;
+}
+template <typename T, int BN>
+static void launch_conv3x3_halo(icl_ctx *ctx, conv_args &a, int npw)
+{
+    hipStream_t strm = ctx->cur_stream ? ctx->cur_stream : ctx->stream;
+    a.gy = a.Cout / BN;
+    if (conv3x3_halo_lds<BN>(npw, 3) <= 80 * 1024) {
+        icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, BN, 3>, (int)conv3x3_halo_lds<BN>(HALO_MAXP, 3));
+        hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, 3>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<BN>(npw, 3), strm, a, npw);
+    } else {
+        icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, BN, 2>, (int)conv3x3_halo_lds<BN>(HALO_MAXP, 2));
+        hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, 2>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<BN>(npw, 2), strm, a, npw);
+    }
 }
 
 template <int BN>
@@ -1028,19 +1052,13 @@ static int launch_conv_t(icl_ctx *ctx, conv_args a)
     const bool early = mode != 0;
     const bool wide = a.Cout % 128 == 0;
     icl_prof_scope ps(ctx, wide ? ICL_K_CONV : ICL_K_CONV64, 2.0 * (double)a.M * a.Cout * a.K, 0.0);
-    if (mode == 1 && !a.X2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W) {
+    // (Cin = 64, stage 1: one channel chunk, 9 short k-steps per tile -- nothing to hide the halo fetch behind, the implicit-GEMM
+    // kernel's fully pipelined staging is 3-5 % faster there although it moves three times the bytes)
+    if (mode == 1 && !a.X2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && a.Cin >= 128) {
         const int npw = conv3x3_halo_npw(a.W); // every 3x3 layer of ResNet50 (W = 56, 28, 14, 7) fits
         if (npw) {
-            hipStream_t strm = ctx->cur_stream ? ctx->cur_stream : ctx->stream;
-            if (wide) {
-                a.gy = a.Cout / 128;
-                icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, 128>, (int)conv3x3_halo_lds<128>(HALO_MAXP));
-                hipLaunchKernelGGL((conv3x3_halo_kernel<T, 128>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<128>(npw), strm, a, npw);
-            } else {
-                a.gy = a.Cout / 64;
-                icl_lds_optin(ctx, (const void *)conv3x3_halo_kernel<T, 64>, (int)conv3x3_halo_lds<64>(HALO_MAXP));
-                hipLaunchKernelGGL((conv3x3_halo_kernel<T, 64>), dim3((unsigned)(a.gx * a.gy)), dim3(256), conv3x3_halo_lds<64>(npw), strm, a, npw);
-            }
+            if (wide) launch_conv3x3_halo<T, 128>(ctx, a, npw);
+            else launch_conv3x3_halo<T, 64>(ctx, a, npw);
             ICL_HIP(ctx, hipGetLastError());
             return ICL_OK;
         }

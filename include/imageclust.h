@@ -112,8 +112,9 @@ int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int C
 /* ---- several GPUs behind one handle ------------------------------------------------------------------
  * workflow.go:89,161 run in ONE process: a group drives ndev contexts from ndev host threads.  embed shards the images by
  * contiguous index ranges; cluster computes the initial distance rows (clustering.go:61-73) on every GPU in area-balanced
- * runs of 128-row tile rows, copies each span device-to-device into GPU 0's packed triangle and runs the exact merge loop
- * on GPU 0.  Outputs are bit-identical to the single-GPU calls.  devices[] entries may repeat (tests on a 1-GPU box). */
+ * runs of 128-row tile rows, copies each span device-to-device into GPU 0 (staging memory, then laid out into its distance
+ * matrix) and runs the exact merge loop on GPU 0.  Outputs are bit-identical to the single-GPU calls.  devices[] entries may
+ * repeat (tests on a 1-GPU box). */
 typedef struct icl_group icl_group;
 int icl_group_create(const int32_t *devices, int32_t ndev, icl_group **out);
 void icl_group_destroy(icl_group *g);
@@ -126,14 +127,24 @@ int icl_group_load_synthetic(icl_group *g, uint64_t seed);
 int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
 int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                       int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+/* workflow.go:84-94 in ONE call -- createEmbeddings (:149-185) then PerformClusteringWithConstraints (:89) -- with the
+ * embeddings staying on the GPUs in between: every GPU embeds its shard of the n images (2048-d pooled head) into its own copy
+ * of E, the shards are exchanged by peer copies (xGMI), the distance rows are built on all GPUs and the merge loop runs on
+ * GPU 0.  Nothing crosses PCIe between embed and cluster.  E_out (host, n x 2048) may be NULL.  Bit-identical to
+ * icl_embed_u8 + icl_cluster on one GPU. */
+int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update,
+                            float *E_out, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 
 /* The building blocks of the above, for callers that bring their own transport (bench.py: one process per GPU, RCCL
- * send/recv).  Rows [row_lo, row_hi) of the packed lower triangle are ONE contiguous span of floats. */
+ * send/recv).  TRANSPORT FORMAT of distance rows: rows [row_lo, row_hi) of the packed lower triangle (row r = r floats, padded
+ * to 4) are ONE contiguous span of floats.  The clustering GPU receives spans into staging buffers (icl_ward_span_ptr: a
+ * transport writes there; icl_ward_deposit_dev: or has them copied) and lays them out into its distance matrix -- whose rows
+ * and columns are recycled during the merge loop (4 n^2 bytes, ward.hip) -- at the next icl_cluster_prefilled_dev. */
 int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi); /* area-balanced, whole 128-row tile rows */
 int icl_ward_span(int64_t row_lo, int64_t row_hi, int64_t *float_off, int64_t *float_cnt);             /* where that span sits / how long it is */
 int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int64_t row_lo, int64_t row_hi, float *d_span);
 int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d);                                              /* allocate the clustering workspace */
-int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt);  /* receive foreign spans here */
+int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt);  /* staging buffer of those rows: receive foreign spans here */
 int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span);           /* ... or copy them in */
 int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                               int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);

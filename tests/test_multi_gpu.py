@@ -51,6 +51,32 @@ def test_group_embed_and_cluster_equal_single_gpu(L):
         ctx.close()
 
 
+def test_group_embed_cluster_keeps_embeddings_on_the_gpus(L):
+    """icl_group_embed_cluster = workflow.go:84-94 in one call: shards embedded on three contexts, E assembled by peer copies
+    on the devices, distance rows on all three, merge loop on context 0.  E, ids and member order must equal embed_u8 +
+    cluster on one context bit for bit -- for a job large enough to be dealt out (n >= 768) and for a small one that is not."""
+    ctx = L.Context(0)
+    ctx.load_synthetic(1)
+    g = L.Group([0, 0, 0])
+    try:
+        g.load_synthetic(1)
+        for n, mn, mx in [(801, 5, 50), (100, 3, 6)]:
+            imgs = L.synth_images(20250217, 11, n, L.SYNTH_STRUCTURED)
+            want = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_BF16)
+            c1, r1, n1 = ctx.cluster(want, mn, mx)
+            E, cid, rank, nc = g.embed_cluster(imgs, mn, mx, L.PREC_BF16)
+            assert np.array_equal(E.view(np.uint32), want.view(np.uint32))
+            assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1)
+        _, cid, rank, nc = g.embed_cluster(imgs, 3, 6, L.PREC_BF16, want_E=False)
+        assert nc == n1 and np.array_equal(cid, c1)
+        with pytest.raises(L.ICLError) as ei:
+            g.embed_cluster(imgs[:10], 4, 4)
+        assert ei.value.code == L.ICL_ERR_CONSTRAINT
+    finally:
+        g.close()
+        ctx.close()
+
+
 def test_distance_row_spans_are_the_rows_of_the_matrix(L):
     import torch
 
