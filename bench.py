@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--max-size", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--embed-only", action="store_true", help="configs[3]: embed throughput without clustering")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N=1: run the distance rows of already-embedded images on a side stream beside the later forward passes "
+                         "(icl_embed_cluster_dev's ICL_FUSE_OVERLAP).  Off by default: measured at 100 000 images the two do not "
+                         "co-execute productively (embed + distances 1 881 ms overlapped, 1 859 ms one after the other; DESIGN.md 5)")
     ap.add_argument("--prec", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: bf16 MFMA with fp32 accumulate (BASELINE.json configs[1], the default); fp32: f32 MFMA, the parity "
                          "path whose embeddings meet 1e-4 against the fp32 restatement (157.3 TFLOP/s matrix peak)")
@@ -187,6 +191,15 @@ def main():
     keep = {}
 
     def step():
+        if world == 1 and not args.embed_only:
+            # one GPU: workflow.go:84-94 as ONE call of the engine (embed -> distance rows -> merge loop, stages overlapped inside the context)
+            keep["E_full"] = E_local
+            cid, mrank, nc = ctx.embed_cluster_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), args.min_size, args.max_size, PREC, update,
+                                                   overlap=args.overlap)
+            st = ctx.last_stage_ms()
+            result.update(embed_ms=st["embed_ms"], dist_ms=st["dist_ms"], merge_ms=st["merge_ms"], n_clusters=nc, merges=len(ctx.last_merges()),
+                          dropped=int((cid < 0).sum()))
+            return
         ctx.embed_u8_dev(imgs.data_ptr(), n_local, E_local.data_ptr(), DIM, PREC)  # returns with the stream idle
         st = ctx.last_stage_ms()
         result["embed_ms"] = st["embed_ms"]
@@ -368,6 +381,8 @@ def main():
                        "ward_update": "none (embed only)" if args.embed_only else "exact (ids bit-identical to the reference)" if args.update == "exact"
                        else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
+            "stages_note": ("N=1: embed_ms includes the distance rows that ran beside the forward passes on a side stream; dist_ms is what was left "
+                            "(tables, centroid transpose, initial row minima)" if world == 1 and not args.embed_only and args.overlap else ""),
             "ward": {k: v for k, v in result.items() if not k.endswith("_ms")},
             "roofline": roof,
             ("roofline_conv" if ward_dominates else "roofline_ward_update"): (conv_roof if ward_dominates else ward_roof),

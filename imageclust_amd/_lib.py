@@ -72,6 +72,7 @@ SYMBOLS = [
     ("icl_group_load_synthetic", _int, [_vp, C.c_uint64]),
     ("icl_group_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_group_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_embed_cluster_dev", _int, [_vp, _vp, _i64, _int, _i32, _i32, _int, _int, _vp, _vp, _vp, _pi32]),
     ("icl_group_embed_cluster", _int, [_vp, _vp, _i64, _int, _i32, _i32, _int, _vp, _vp, _vp, _pi32]),
     ("icl_ward_rows_partition", _int, [_i64, _i32, _i32, _pi64, _pi64]),
     ("icl_ward_span", _int, [_i64, _i64, _pi64, _pi64]),
@@ -330,6 +331,16 @@ class Context:
         nc = _i32()
         check(self.h, self.L.icl_cluster_dev(self.h, _vp(d_E), n, d, min_size, max_size, update, cid.ctypes.data,
                                              rank.ctypes.data, C.byref(nc)))
+        return cid[:n], rank[:n], nc.value
+
+    def embed_cluster_dev(self, d_imgs, n, d_E, min_size, max_size, prec=PREC_BF16, update=UPDATE_EXACT, overlap=True):
+        """workflow.go:84-94 on one GPU: embed n resident images into d_E (n x 2048, device) and cluster them; overlap=True runs
+        the distance rows of already-embedded images beside the later forward passes."""
+        cid = np.full(max(n, 1), -1, np.int32)
+        rank = np.full(max(n, 1), -1, np.int32)
+        nc = _i32()
+        check(self.h, self.L.icl_embed_cluster_dev(self.h, _vp(d_imgs), n, prec, min_size, max_size, update, 1 if overlap else 0, _vp(d_E),
+                                                   cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
 
     # ---- distance tiles over several GPUs (building blocks; imageclust_amd/distributed.py and Group use them) ----

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,6 +32,10 @@ struct icl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream: the second forward pass in flight (resnet.hip)
+    hipStream_t stream3 = nullptr; // side stream: distance rows of already-embedded images beside the forward passes (icl_embed_cluster_dev; created on first use)
+    hipEvent_t ev_s3 = nullptr;
+    // called by the embed loop after it has enqueued a batch: (first image, images, event recorded behind the batch); set only by icl_embed_cluster_dev
+    std::function<int(int64_t, int64_t, hipEvent_t)> embed_hook;
     hipStream_t cur_stream = nullptr; // stream the convolution launches of the forward pass being enqueued go to (nullptr: stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mu;

@@ -79,6 +79,8 @@ extern "C" void icl_destroy(icl_ctx *ctx)
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->ev_s3) (void)hipEventDestroy(ctx->ev_s3);
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
     delete ctx;

@@ -1266,7 +1266,9 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     return ICL_OK;
 }
 
-static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out)
+int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out); // also called by icl_embed_cluster_dev (ward.hip)
+static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out) { return icl_embed_dev_locked(ctx, d_img, n, head, prec, d_out); }
+int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out)
 {
     if (!ctx->model) return icl_fail(ctx, ICL_ERR_NOMODEL, "no model loaded (call icl_model_load_* first)");
     if (head != ICL_HEAD_POOLED && head != ICL_HEAD_DENSE0) return icl_fail(ctx, ICL_ERR_ARG, "head must be 2048 or 1000");
@@ -1315,6 +1317,7 @@ static int embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int h
                                              : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm);
         if (rc) return rc;
         ICL_HIP(ctx, hipEventRecord(ev, strm));
+        if (ctx->embed_hook) ICL_TRY(ctx->embed_hook(i, B, ev)); // rows [i, i + B) of d_out are complete once ev has fired
     }
     ctx->cur_stream = nullptr;
     for (int l = 1; l < lanes; ++l) { // join

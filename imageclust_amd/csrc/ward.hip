@@ -157,26 +157,48 @@ void icl_ward_free(icl_ctx *ctx)
 #define DT_KC 16
 #define DT_LD (DT_TILE + 4)
 
-__device__ __forceinline__ void tri_decode(int64_t b, int &ti, int &tj)
+
+// Tile order of a launch over tile rows [tr_lo, tr_hi) (tile row ti holds the tiles tj = 0 .. ti): BANDS of 8 tile rows; inside a
+// band the tiles left of the band's first diagonal tile go column by column -- 8 consecutive tiles share one 128-row panel of X
+// as their column operand, consecutive columns share the band's 8 row panels -- then the band's triangular cap.  With the
+// XCD-aware dealing below, the ~100 tiles an XCD runs at a time touch ~20 panels instead of ~100 (the kernel streams k-chunks,
+// so tiles that run together read the same cache lines at about the same time): the row-major order fetched 21x the
+// algorithmic bytes at N = 100 000 (profiles/r02c_pmc_traffic.json).
+__device__ __forceinline__ void band_decode(int64_t b, int64_t tr_lo, int64_t tr_hi, int &ti, int &tj)
 {
-    // b = ti*(ti+1)/2 + tj, 0 <= tj <= ti
-    int64_t t = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((t + 1) * (t + 2) / 2 <= b) ++t;
-    while (t * (t + 1) / 2 > b) --t;
-    ti = (int)t;
-    tj = (int)(b - t * (t + 1) / 2);
+    auto before = [&](int64_t q) { return 32 * q * q + q * (8 * tr_lo + 4); }; // tiles of the bands in front of band q
+    const double c1 = 8.0 * (double)tr_lo + 4.0;
+    int64_t q = (int64_t)((-c1 + sqrt(c1 * c1 + 128.0 * (double)b)) / 64.0);
+    while (before(q + 1) <= b) ++q;
+    while (q > 0 && before(q) > b) --q;
+    const int64_t r0 = tr_lo + 8 * q;
+    const int64_t h = tr_hi - r0 < 8 ? tr_hi - r0 : 8;
+    int64_t r = b - before(q);
+    const int64_t rect = h * (r0 + 1);
+    if (r < rect) {
+        tj = (int)(r / h);
+        ti = (int)(r0 + r % h);
+        return;
+    }
+    r -= rect; // the cap: row r0 + a holds the columns r0 + 1 .. r0 + a
+    int a = 1;
+    while ((int64_t)a * (a + 1) / 2 <= r) ++a;
+    ti = (int)(r0 + a);
+    tj = (int)(r0 + 1 + (r - (int64_t)a * (a - 1) / 2));
 }
 
 // mode 0: packed lower triangle (rowoff); mode 1: dense symmetric n x n with leading dimension ld.
 template <int MODE>
 __global__ __launch_bounds__(256) void ward_dist_exact_kernel(const float *__restrict__ X, const int32_t *__restrict__ sizes,
                                                              int64_t n, int d, float *__restrict__ out,
-                                                             const int64_t *__restrict__ rowoff, int64_t ld, int64_t block_base)
+                                                             const int64_t *__restrict__ rowoff, int64_t ld, int64_t tr_lo, int64_t tr_hi)
 {
     __shared__ __attribute__((aligned(16))) float As[DT_KC][DT_LD];
     __shared__ __attribute__((aligned(16))) float Bs[DT_KC][DT_LD];
     int ti, tj;
-    tri_decode(block_base + blockIdx.x, ti, tj); // block_base > 0: a run of whole tile rows (a rank's share of the triangle)
+    // XCD-aware dealing: workgroups go round-robin over the 8 XCDs (private L2s); each XCD takes a contiguous run of the launch's
+    // tiles in band order.  [tr_lo, tr_hi): a run of whole tile rows (the whole triangle, or a rank's share of it)
+    band_decode(xcd_remap((int)blockIdx.x, (int)gridDim.x), tr_lo, tr_hi, ti, tj);
     const int64_t i0 = (int64_t)ti * DT_TILE, j0 = (int64_t)tj * DT_TILE;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -2929,8 +2951,9 @@ extern "C" int icl_calc_optimal_clusters(int64_t total, int64_t min_size, int64_
 // Tile rows [tr_lo, tr_hi) of the lower triangle (tile row ti holds ti+1 tiles of 128 x 128 pairs).  In mode 0 `out` is the
 // address row 0 of the packed triangle WOULD have: a caller that holds only the span of its own rows passes span - rowoff[first row].
 static int launch_dist_exact_rows(icl_ctx *ctx, const float *d_X, const int32_t *d_sizes, int64_t n, int d, float *out,
-                                  const int64_t *rowoff, int64_t ld, int mode, int64_t tr_lo, int64_t tr_hi)
+                                  const int64_t *rowoff, int64_t ld, int mode, int64_t tr_lo, int64_t tr_hi, hipStream_t strm = nullptr)
 {
+    if (!strm) strm = ctx->stream;
     if (n <= 0 || tr_hi <= tr_lo) return ICL_OK;
     const int64_t b_lo = tr_lo * (tr_lo + 1) / 2, nblocks = tr_hi * (tr_hi + 1) / 2 - b_lo;
     if (nblocks > 0x7fffffffLL) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "distance tile grid too large (n=%lld)", (long long)n);
@@ -2938,11 +2961,11 @@ static int launch_dist_exact_rows(icl_ctx *ctx, const float *d_X, const int32_t 
     const double pairs = 0.5 * ((double)r_hi * (double)(r_hi - 1) - (double)r_lo * (double)(r_lo - 1));
     icl_prof_scope ps(ctx, ICL_K_DIST_EXACT, pairs * 3.0 * d, 4.0 * r_hi * d + 4.0 * pairs);
     if (mode == 0)
-        hipLaunchKernelGGL(ward_dist_exact_kernel<0>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
-                           out, rowoff, ld, b_lo);
+        hipLaunchKernelGGL(ward_dist_exact_kernel<0>, dim3((unsigned)nblocks), dim3(256), 0, strm, d_X, d_sizes, n, d,
+                           out, rowoff, ld, tr_lo, tr_hi);
     else
-        hipLaunchKernelGGL(ward_dist_exact_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, d_X, d_sizes, n, d,
-                           out, rowoff, ld, b_lo);
+        hipLaunchKernelGGL(ward_dist_exact_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, strm, d_X, d_sizes, n, d,
+                           out, rowoff, ld, tr_lo, tr_hi);
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
 }
@@ -3520,6 +3543,69 @@ extern "C" int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+}
+
+// workflow.go:84-94 on ONE GPU in one call: createEmbeddings (:149-185, here the batched forward passes over n resident images)
+// followed by PerformClusteringWithConstraints (:89) -- with the stages OVERLAPPED inside the context (flags & ICL_FUSE_OVERLAP):
+// the exact distance rows of a tile row only need the embeddings of the images up to that row, so they are launched on a third
+// stream as soon as the batch that completes them has been enqueued (behind its event), and run on the vector ALUs beside the
+// later batches' MFMA kernels.  Results are those of icl_embed_u8_dev + icl_cluster_dev, bit for bit: the same kernels compute
+// the same rows, only earlier.  d_E (device, n x 2048) receives the pooled embeddings.
+int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out); // resnet.hip
+extern "C" int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int prec, int32_t min_size, int32_t max_size, int update, int flags,
+                                     float *d_E, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    if (!ctx || n < 0 || !n_clusters || (n && (!d_img || !d_E || !cluster_id || !member_rank)))
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_cluster_dev: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    icl_device_guard g(ctx->device);
+    const int32_t d = ICL_HEAD_POOLED;
+    int64_t kk = 0;
+    const bool overlap = (flags & ICL_FUSE_OVERLAP) && update == ICL_UPDATE_EXACT && n >= 2 * DT_TILE && !ctx->prof_mask &&
+                         icl_calc_optimal_clusters(n, min_size, max_size, &kk) == ICL_OK;
+    if (!overlap) {
+        ICL_TRY(icl_embed_dev_locked(ctx, d_img, n, d, prec, d_E));
+        return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+    }
+    ICL_TRY(ward_ensure(ctx, n, d));
+    icl_ward_ws *w = ctx->ward;
+    if (!ctx->stream3) {
+        ICL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        ICL_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_s3, hipEventDisableTiming));
+    }
+    hipStream_t s3 = ctx->stream3;
+    // the distance kernel addresses the singleton rows through rowoff: set the tables up first (cluster_locked below runs the
+    // same kernel again on the main stream, after s3 has drained: same values)
+    ICL_HIP(ctx, hipEventRecord(ctx->ev_s3, ctx->stream));
+    ICL_HIP(ctx, hipStreamWaitEvent(s3, ctx->ev_s3, 0)); // whatever was queued on the main stream (an earlier cluster call) comes first
+    {
+        const int64_t cnt = std::max(std::max(w->S, w->M), w->ld);
+        hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, s3, n, w->S, w->M, w->ld,
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)0);
+    }
+    int64_t next_tr = 0;
+    const int64_t ntr = icl_ceil_div(n, DT_TILE);
+    ctx->embed_hook = [&](int64_t first, int64_t cnt, hipEvent_t ev) -> int {
+        // batches are enqueued in image order and s3 is in order: once it has waited for this batch's event it has waited for
+        // every earlier batch too, i.e. rows [0, first + cnt) of d_E are complete
+        ICL_HIP(ctx, hipStreamWaitEvent(s3, ev, 0));
+        const int64_t ready = first + cnt, tr_hi = ready >= n ? ntr : ready / DT_TILE;
+        if (tr_hi > next_tr) {
+            ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0, next_tr, tr_hi, s3));
+            next_tr = tr_hi;
+        }
+        return ICL_OK;
+    };
+    int rc = icl_embed_dev_locked(ctx, d_img, n, d, prec, d_E);
+    ctx->embed_hook = nullptr;
+    if (rc == ICL_OK && next_tr != ntr) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_embed_cluster_dev: %lld of %lld distance tile rows were launched", (long long)next_tr, (long long)ntr);
+    hipError_t e = hipEventRecord(ctx->ev_s3, s3);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_s3, 0);
+    if (e != hipSuccess || rc != ICL_OK) {
+        (void)hipStreamSynchronize(s3);
+        return rc != ICL_OK ? rc : icl_fail(ctx, ICL_ERR_HIP, "icl_embed_cluster_dev: %s", hipGetErrorString(e));
+    }
+    return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, 0, 0); // every row is in place
 }
 
 extern "C" int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,

@@ -177,6 +177,12 @@ int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t min_
                 int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,
                     int update, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+/* workflow.go:84-94 on one GPU in one call: embed n resident images (2048-d pooled head, into d_E: device, n x 2048) and
+ * cluster them.  flags & ICL_FUSE_OVERLAP: the distance rows of already-embedded images are computed on a side stream of the
+ * context while later batches embed (same kernels, same results as icl_embed_u8_dev + icl_cluster_dev, bit for bit). */
+enum { ICL_FUSE_OVERLAP = 1 };
+int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update, int flags,
+                          float *d_E, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
  * cluster, creation id of the lower-position one); returns the number of merges performed. */
 int64_t icl_last_merges(icl_ctx *ctx, int32_t *pairs, int64_t cap_pairs);

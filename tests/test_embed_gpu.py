@@ -93,6 +93,25 @@ def test_conv_partial_tiles_and_small_batch(ctx, L):
     assert np.abs(y - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
 
 
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 7, 128, 128), (5, 14, 128, 64), (1, 28, 192, 128), (2, 9, 256, 128)])
+def test_conv3x3_halo_kernel_ragged_tiles_and_odd_shapes(ctx, L, B, H, cin, cout):
+    """conv3x3_halo_kernel (3x3 / stride 1 / pad 1 with Cin >= 128: the LDS-staged halo tile) on shapes ResNet50 does not have:
+    ragged last tiles (M = 147, 980), tiles that span several images (7x7, 9x9: image borders inside a tile, zero padding
+    between images), a width that is no power of two, three channel chunks, Cout = 64.  fp32 against the oracle at 1e-4;
+    bf16 against the oracle on bf16-rounded operands."""
+    rng = np.random.default_rng(B * 100 + H)
+    x = rng.standard_normal((B, H, H, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    y = ctx.conv2d_fused(x, w, sc, sh, 1, 1, None, True, L.PREC_FP32)
+    r = ref_conv(x, w, sc, sh, 1, 1, None, True)
+    assert np.abs(y - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
+    yb = ctx.conv2d_fused(x, w, sc, sh, 1, 1, None, True, L.PREC_BF16)
+    rb = ref_conv(bf16_round(x), bf16_round(w), sc, sh, 1, 1, None, True)
+    assert np.abs(yb - rb).max() <= 1.2e-2 * max(1.0, np.abs(rb).max())
+
+
 def test_full_forward_fp32_matches_oracle(ctx, L, blob):
     imgs = np.concatenate([L.synth_images(20250217, 0, 2, L.SYNTH_NOISE), L.synth_images(20250217, 7, 1, L.SYNTH_STRUCTURED)])
     ctx.set_batch(2)  # 3 images at batch 2: exercises the ragged last batch

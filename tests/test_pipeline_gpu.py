@@ -168,3 +168,35 @@ def test_batch_leader_failure_releases_every_caller(ctx, L, tmp_path):
     assert time.perf_counter() - t0 < 0.4
     assert np.array_equal(ctx.embed_file(paths[1], L.HEAD_DENSE0), want[1])
     ctx.set_file_options(L.PREC_FP32, 2000, 256)
+
+
+def test_fused_embed_cluster_with_overlapped_distance_rows_equals_the_separate_calls(ctx, L):
+    """icl_embed_cluster_dev (workflow.go:84-94 as one call): with ICL_FUSE_OVERLAP the distance rows of already-embedded images
+    are computed on a side stream while later batches embed.  Embeddings, cluster ids, member order and the merge log must equal
+    icl_embed_u8_dev followed by icl_cluster_dev bit for bit -- with and without the overlap, for a size with a ragged last batch
+    and a ragged last tile row."""
+    n = 1411
+    d_img = ctx.malloc(n * L.IMG_BYTES)
+    d_E = ctx.malloc(n * 2048 * 4)
+    d_E2 = ctx.malloc(n * 2048 * 4)
+    try:
+        ctx.synth_images_dev(20250217, 5, n, L.SYNTH_STRUCTURED, d_img)
+        ctx.embed_u8_dev(d_img, n, d_E, L.HEAD_POOLED, L.PREC_BF16)
+        cid, rank, nc = ctx.cluster_dev(d_E, n, 2048, 5, 50)
+        log = ctx.last_merges().copy()
+        vals = ctx.last_merge_values().copy()
+        want = np.empty((n, 2048), np.float32)
+        ctx.d2h(want, d_E)
+        for overlap in (True, False):
+            c2, r2, n2 = ctx.embed_cluster_dev(d_img, n, d_E2, 5, 50, L.PREC_BF16, overlap=overlap)
+            got = np.empty((n, 2048), np.float32)
+            ctx.d2h(got, d_E2)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), overlap
+            assert n2 == nc and np.array_equal(c2, cid) and np.array_equal(r2, rank), overlap
+            assert np.array_equal(ctx.last_merges(), log) and np.array_equal(ctx.last_merge_values().view(np.uint32), vals.view(np.uint32)), overlap
+        with pytest.raises(L.ICLError) as ei:
+            ctx.embed_cluster_dev(d_img, 10, d_E2, 4, 4, L.PREC_BF16)
+        assert ei.value.code == L.ICL_ERR_CONSTRAINT
+    finally:
+        for p in (d_img, d_E, d_E2):
+            ctx.free(p)
