@@ -72,6 +72,7 @@ SYMBOLS = [
     ("icl_group_load_synthetic", _int, [_vp, C.c_uint64]),
     ("icl_group_embed_u8", _int, [_vp, _vp, _i64, _int, _int, _vp]),
     ("icl_group_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
+    ("icl_set_ward_options", _int, [_vp, _int]),
     ("icl_embed_cluster_dev", _int, [_vp, _vp, _i64, _int, _i32, _i32, _int, _int, _vp, _vp, _vp, _pi32]),
     ("icl_group_embed_cluster", _int, [_vp, _vp, _i64, _int, _i32, _i32, _int, _vp, _vp, _vp, _pi32]),
     ("icl_ward_rows_partition", _int, [_i64, _i32, _i32, _pi64, _pi64]),
@@ -333,6 +334,10 @@ class Context:
                                              rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
 
+    def set_ward_options(self, dist_mode=0):
+        """0 auto, 1 exact initial distances, 2 distance bounds + on-demand exact evaluation (include/imageclust.h ICL_DIST_*)."""
+        check(self.h, self.L.icl_set_ward_options(self.h, dist_mode))
+
     def embed_cluster_dev(self, d_imgs, n, d_E, min_size, max_size, prec=PREC_BF16, update=UPDATE_EXACT, overlap=True):
         """workflow.go:84-94 on one GPU: embed n resident images into d_E (n x 2048, device) and cluster them; overlap=True runs
         the distance rows of already-embedded images beside the later forward passes."""
@@ -480,7 +485,7 @@ def calc_optimal_clusters(total, min_size, max_size):
 
 
 def decode_image_file(path):
-    """IMRead (embeddings.go:50) for baseline or progressive JPEG / binary PPM -> h x w x 3 u8 RGB."""
+    """IMRead (embeddings.go:50) for baseline or progressive JPEG / PNG / binary PPM -> h x w x 3 u8 RGB."""
     L = load()
     w, h = _i32(), _i32()
     rc = L.icl_decode_image_file(os.fsencode(path), None, 0, C.byref(w), C.byref(h))

@@ -42,6 +42,7 @@ struct icl_ctx {
     std::string err;
     hipDeviceProp_t prop;
     int batch = 256;
+    int ward_dist = 0; // icl_set_ward_options: 0 auto, 1 every initial distance by the exact kernel, 2 distance bounds + on-demand exact evaluation
     // profiling
     int prof_mask = 0;
     icl_prof_slot prof[ICL_K_NCLASS];

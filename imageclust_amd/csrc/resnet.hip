@@ -1506,11 +1506,13 @@ static int read_ppm(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, i
         ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
     }
     fclose(f);
-    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only baseline JPEG and binary PPM (P6, maxval 255) are decoded by this build", path);
+    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only JPEG (Huffman), PNG (non-interlaced) and binary PPM (P6, maxval 255) are decoded by this build", path);
     return ICL_OK;
 }
 
 int icl_jpeg_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H, int &orient); // jpeg_decode.hip
+bool icl_is_png(const uint8_t *data, size_t len);                                                                                                  // png_decode.hip
+int icl_png_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *path, std::vector<uint8_t> &rgb, int &W, int &H);
 
 // cv::imread rotates / mirrors the decoded pixels by the file's EXIF orientation (OpenCV ExifTransform): 2 mirror
 // horizontally, 3 rotate 180, 4 mirror vertically, 5 transpose, 6 rotate 90 clockwise, 7 transverse, 8 rotate 90 counter-clockwise.
@@ -1540,14 +1542,24 @@ static void apply_exif_orientation(std::vector<uint8_t> &rgb, int &w, int &h, in
     h = dh;
 }
 
-// IMRead(IMReadColor) of embeddings.go:50 for the two formats this build decodes.
+// IMRead(IMReadColor) of embeddings.go:50 for the formats this build decodes: JPEG, PNG, binary PPM.
 static int read_image(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path); // embeddings.go:52
-    unsigned char magic[2] = {0, 0};
-    const size_t got = fread(magic, 1, 2, f);
-    if (got == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
+    unsigned char magic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t got = fread(magic, 1, 8, f);
+    if (got == 8 && icl_is_png(magic, 8)) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> file((size_t)std::max<long>(sz, 0));
+        const bool ok = sz > 0 && fread(file.data(), 1, file.size(), f) == file.size();
+        fclose(f);
+        if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. The image file might be corrupt or unreadable", path);
+        return icl_png_decode(ctx, file.data(), file.size(), path, rgb, w, h);
+    }
+    if (got >= 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
         fseek(f, 0, SEEK_END);
         const long sz = ftell(f);
         fseek(f, 0, SEEK_SET);

@@ -37,6 +37,9 @@
 #include <type_traits>
 
 int icl_dist_mfma_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, float *d_out, const int64_t *d_rowoff, int64_t ld); // distance_mfma.hip
+int icl_dist_center_launch(icl_ctx *ctx, const float *d_E, int64_t n, int d, int K, double *d_colsum, float *d_Ec, float *d_nrm, hipStream_t strm);
+int icl_dist_bound_launch(icl_ctx *ctx, const float *d_Ec, const float *d_nrm, const void *d_zero, int64_t n, int K, float ceps, float gam, float *d_out,
+                          const int64_t *d_rowoff, int64_t tr_lo, int64_t tr_hi, hipStream_t strm);
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -73,6 +76,7 @@ struct ward_batch_state {
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
     unsigned long long dbg[8], dbg_t0, dbg2[3];
+    unsigned long long rf_stat[8];   // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
     int32_t blk_next, blk_pad;       // the persistent main workgroups' block counter (zeroed every step by ward_interleave_kernel)
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
     int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
@@ -116,6 +120,9 @@ struct icl_ward_ws {
     int32_t *mcid = nullptr;   // [ld] by column: creation id of the occupant
     float *Dtri = nullptr;     // (N + WB_K) rows x ld floats
     int64_t ld = 0;            // row pitch in floats (N rounded up to 64)
+    float *nrm = nullptr;      // [capN] |E[r] - mu|^2 of the singletons: the scans' upper bounds of flagged entries (distance bounds)
+    double *colsum = nullptr;  // [capD] column sums of E
+    void *zero = nullptr;      // 256 zero bytes (LDS-DMA source of rows beyond n)
     int64_t dtri_floats = 0;
     std::vector<std::pair<std::pair<int64_t, int64_t>, float *>> staged; // foreign distance rows [lo, hi) in transport (packed) format, unpacked by the next cluster call
     int32_t *merges = nullptr; // [2*N]
@@ -129,7 +136,10 @@ struct icl_ward_ws {
     hipGraphExec_t graph_exec = nullptr;
     int graph_max_size = -1;
     int graph_lw = -1;
-    bool upd_attr = false, wx_attr = false; // the kernels' > 64 KB dynamic-LDS opt-in has been made on this context's device
+    const float *graph_E = nullptr; // the captured launches carry the embeddings' address (scans that evaluate flagged entries): part of the graph's key
+    float graph_ceps = -1.0f;
+    size_t upd_attr_bytes = 0; // the kernels' > 64 KB dynamic-LDS opt-in made on this context's device
+    bool wx_attr = false;
 };
 
 void icl_ward_free(icl_ctx *ctx)
@@ -140,7 +150,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero};
     for (auto &sp : w->staged)
         if (sp.second) (void)hipFree(sp.second);
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
@@ -421,14 +431,10 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
 {
     bv = ICL_MAXF;
     bi = -1;
-    int e8[2 * WB_K];
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) e8[z] = z < nex ? ex[z] : -1;
     auto visit = [&](float v, int m, int c) {
         if (m > 0 && m + my_size <= max_size && c < my_id && (v < bv || (v == bv && c < bi))) {
-            bool ex_hit = false;
-#pragma unroll
-            for (int z = 0; z < 2 * WB_K; ++z) ex_hit |= e8[z] == c;
+            bool ex_hit = false; // (the list is read where it lives -- LDS -- on the rare candidates only: no registers held across the row)
+            for (int z = 0; z < nex; ++z) ex_hit |= ex[z] == c;
             if (!ex_hit) {
                 bv = v;
                 bi = c;
@@ -458,11 +464,265 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
     for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) visit(row[q], msz[q], mcid[q]);
 }
 
+// ---- distance BOUNDS in singleton rows (distance_mfma.hip, "Distance BOUNDS for the exact mode") ---------------------------------
+// ComputeInitialDistanceMatrix may be filled with proven LOWER bounds of the Ward values instead of the values: an entry with
+// the sign bit set says "the reference's value is >= |entry|" (and <= wupper(|entry|)).  Only singleton rows ever hold such
+// entries (the update kernels write values), and only against singleton columns.  A scan of such a row finds the best VALUE and
+// the smallest UPPER bound among the valid entries, evaluates exactly -- the reference's own sequential fp32 expression on the
+// two embeddings -- every flagged entry whose lower bound does not exceed that threshold, writes the values back, and returns the
+// first minimum among values only.  An entry left flagged is strictly above the threshold, hence strictly above the minimum: it
+// can neither win nor tie.  Nothing a comparison sees is ever a bound.
+struct wrefine {
+    const float *E;   // [n][d] the embeddings = the singletons' centroids (they never change); nullptr: rows hold values only
+    const float *nrm; // [n] computed |E[r] - mu|^2 (dist_center_kernel)
+    int64_t n;
+    int d;
+    float ceps, gam;  // E_ab = ceps (nrm[a] + nrm[b]) (ceps rounded up on the host); gam = g'
+    unsigned long long *stat; // statistics (may be null): [0] scans, [1] collecting passes, [2] evaluation rounds, [3] entries evaluated
+    float margin;     // a scan also evaluates the flagged entries up to (1 + margin) x its threshold: no effect on the result, it only
+                      // decides how much is made exact ahead of need.  The initial row minima use a generous margin (the evaluations
+                      // of one round run in parallel, one per thread: ~10 us whether 3 or 1000), so that the merge loop's rescans --
+                      // which sit on the update kernel's critical path -- find the near entries exact already
+};
+__device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
+__device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf)
+{
+    // R <= (T + E_ab)(1 + g'),  T - E_ab <= L (1 + 2 g')  (the store rounded L down by at most g' + 3e-7 relative):
+    // R <= (L (1 + 2 g') + 2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
+    return (L * (1.0f + 3.0f * rf.gam) + 2.0001f * rf.ceps * ns) * (1.0f + 2.0f * rf.gam);
+}
+// WardDistance of two SINGLETONS from their embeddings (clustering.go:136-157 with sizes 1, 1): sequential, unfused fp32
+__device__ __forceinline__ float ward_singleton_pair(const float *__restrict__ E, int d, int a, int b)
+{
+    const float *x = E + (int64_t)a * d, *y = E + (int64_t)b * d;
+    float s = 0.0f;
+    if ((d & 3) == 0) {
+        for (int k = 0; k < d; k += 4) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + k), yv = *reinterpret_cast<const float4 *>(y + k);
+            float df = xv.x - yv.x; // clustering.go:139
+            float p = df * df;      // :154 product (rounded)
+            s = s + p;              // :154 sum (rounded), strictly in k order
+            df = xv.y - yv.y;
+            p = df * df;
+            s = s + p;
+            df = xv.z - yv.z;
+            p = df * df;
+            s = s + p;
+            df = xv.w - yv.w;
+            p = df * df;
+            s = s + p;
+        }
+    } else {
+        for (int k = 0; k < d; ++k) {
+            const float df = x[k] - y[k];
+            const float p = df * df;
+            s = s + p;
+        }
+    }
+    const float num = (float)((int64_t)1 * (int64_t)1); // :142
+    const float den = (float)(1 + 1);                    // :143
+    return (num / den) * s;                              // :144
+}
+
+// visits columns [0, len) of a row: f(value, msz, mcid, column) with 4 x 16-byte loads of each stream in flight per lane
+template <typename F>
+__device__ __forceinline__ void ward_row_visit(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid, F &&f)
+{
+    const int64_t nvec = len >> 2;
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+        float4 v[4];
+        int4 m[4], c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + (int64_t)j * blockDim.x;
+            const bool has = q < nvec;
+            v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+            m[j] = has ? reinterpret_cast<const int4 *>(msz)[q] : make_int4(0, 0, 0, 0);
+            c[j] = has ? reinterpret_cast<const int4 *>(mcid)[q] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
+            f(v[j].x, m[j].x, c[j].x, col);
+            f(v[j].y, m[j].y, c[j].y, col + 1);
+            f(v[j].z, m[j].z, c[j].z, col + 2);
+            f(v[j].w, m[j].w, c[j].w, col + 3);
+        }
+    }
+    for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) f(row[q], msz[q], mcid[q], (int)q);
+}
+
+#define WB_REF_CAP 1024
+// scan_row_m for a singleton row that may hold flagged entries; the result is already REDUCED over the workgroup (sv / si:
+// scratch of 16 floats / ints).  Inlined: out of line its LDS scratch pointers degrade to flat accesses and every call spills the
+// caller's live registers (measured: update kernel 258 us per launch with 1.4 calls per step out of line, 234 us inlined with 29).
+// scan_row_min below only comes here when its one-pass optimistic scan finds a BOUND at the row's head (5 % of the scans).
+// (tv, ti) lexicographic minimum, ub and lmin plain minima over the workgroup: ONE pass through LDS (three block_argmin calls cost
+// nine barriers per scan, and the scans sit on the update kernel's critical chain)
+__device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float &lmin, float *sv, int *si)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(tv, off, 64);
+        const int oi = __shfl_down(ti, off, 64);
+        argmin_combine(tv, ti, ov, oi);
+        ub = fminf(ub, __shfl_down(ub, off, 64));
+        lmin = fminf(lmin, __shfl_down(lmin, off, 64));
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float *s2 = reinterpret_cast<float *>(si); // si[0..15]: ti of the waves; the two plain minima go behind sv's 16 values
+    (void)s2;
+    __shared__ float m3[2][16];
+    if (lane == 0) {
+        sv[wid] = tv;
+        si[wid] = ti;
+        m3[0][wid] = ub;
+        m3[1][wid] = lmin;
+    }
+    __syncthreads();
+    float bv = sv[0], bu = m3[0][0], bl = m3[1][0];
+    int bi = si[0];
+    for (int w = 1; w < nw; ++w) { // every thread reduces the <= 16 wave results itself: no second hand-over
+        argmin_combine(bv, bi, sv[w], si[w]);
+        bu = fminf(bu, m3[0][w]);
+        bl = fminf(bl, m3[1][w]);
+    }
+    tv = bv;
+    ti = bi;
+    ub = bu;
+    lmin = bl;
+    __syncthreads(); // sv / si / m3 may be rewritten
+}
+
+__device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                             int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
+                                             const wrefine rf)
+{
+    __shared__ int ref_cnt;
+    __shared__ int ref_col[WB_REF_CAP];
+    auto excluded = [&](int c) { // (read from the caller's list -- LDS -- on the rare candidates only: no registers held across the row)
+        bool hit = false;
+        for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
+        return hit;
+    };
+    const float nme = rf.nrm[my_id];
+    if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
+    for (;;) {
+        // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
+        float tv = ICL_MAXF, ub = ICL_MAXF, lmin = ICL_MAXF;
+        int ti = -1;
+        ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int) {
+            if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
+            if (wflagged(v)) {
+                const float L = fabsf(v);
+                lmin = L < lmin ? L : lmin; // (an excluded entry counted here only costs an empty pass B)
+                if (L < tv && L < ub) { // its upper bound (>= L) can only matter below this thread's best value and best upper bound
+                    const float up = wupper(L, nme + rf.nrm[c], rf); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
+                    if (up < ub && !excluded(c)) ub = up;
+                }
+            } else if (v < tv || (v == tv && c < ti)) {
+                if (!excluded(c)) {
+                    tv = v;
+                    ti = c;
+                }
+            }
+        });
+        block_min3(tv, ti, ub, lmin, sv, si);
+        const float thr = tv < ub ? tv : ub; // the row's minimum is <= thr
+        // lmin == MaxFloat32: no valid flagged entry (bounds are finite, far below MaxFloat32).  lmin > thr: every flagged entry
+        // is strictly above the minimum.  Either way the best value stands.
+        if (lmin == ICL_MAXF || lmin > thr) {
+            bv = tv;
+            bi = ti;
+            return;
+        }
+        const float thr_b = thr < 1e37f ? thr * (1.0f + rf.margin) : thr; // (margin: entries made exact ahead of need)
+        if (threadIdx.x == 0) ref_cnt = 0;
+        if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[1], 1ull);
+        __syncthreads();
+        // pass B: flagged entries whose lower bound does not exceed the threshold
+        ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
+            if (!(m > 0 && m + my_size <= max_size && c < my_id) || !wflagged(v)) return;
+            if (fabsf(v) <= thr_b && !excluded(c)) {
+                const int at = atomicAdd(&ref_cnt, 1);
+                if (at < WB_REF_CAP) ref_col[at] = col;
+            }
+        });
+        __syncthreads();
+        const int total = ref_cnt, m = total < WB_REF_CAP ? total : WB_REF_CAP;
+        if (rf.stat && threadIdx.x == 0 && m > 0) {
+            atomicAdd(&rf.stat[2], 1ull);
+            atomicAdd(&rf.stat[3], (unsigned long long)m);
+        }
+        float rv = ICL_MAXF;
+        int ri = -1;
+        for (int q = threadIdx.x; q < m; q += blockDim.x) {
+            const int col = ref_col[q];
+            const int c = mcid[col]; // == col: a valid flagged entry stands in a singleton's own column
+            const float val = ward_singleton_pair(rf.E, rf.d, my_id, c);
+            row[col] = val; // a value from now on
+            if (val < rv || (val == rv && c < ri)) {
+                rv = val;
+                ri = c;
+            }
+        }
+        block_argmin(rv, ri, sv, si); // (ends with a barrier: ref_cnt may be reset afterwards)
+        argmin_combine(tv, ti, rv, ri);
+        if (total <= WB_REF_CAP) { // every entry of the band is a value now; whatever stayed flagged is strictly above thr >= the minimum
+            bv = tv;
+            bi = ti;
+            return;
+        }
+        __threadfence_block(); // more than WB_REF_CAP entries in the band (heavy ties): go again, the written-back values lower thr
+        __syncthreads();
+    }
+}
+
+// The row scan of every merge-loop kernel: result reduced over the workgroup.
+// Rows that may hold bounds (singleton rows while rf.E is set) first get ONE optimistic pass that costs what scan_row_m costs:
+// a flagged entry competes with its lower bound |v| and wins ties against values.  If a VALUE comes out on top, every bound is
+// strictly above it, so every flagged entry's true value is too: the value is the row's first minimum, exactly as the full
+// procedure would find it.  Only when a bound comes out on top does scan_row_refine run.
+__device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                             int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
+                                             const wrefine &rf)
+{
+    if (!(rf.E && my_id < rf.n)) {
+        scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi);
+        block_argmin(bv, bi, sv, si);
+        return;
+    }
+    // index key: a flagged entry keeps its creation id (< n < 2^29: bounds are only built below that size), a value gets bit 30 set,
+    // so among equal keys a bound wins, then the smaller creation id
+    constexpr int VBIT = 1 << 30;
+    bv = ICL_MAXF;
+    bi = -1;
+    ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int) {
+        const float k = fabsf(v);
+        const int ik = wflagged(v) ? c : (c | VBIT);
+        if (m > 0 && m + my_size <= max_size && c < my_id && (k < bv || (k == bv && ik < bi))) {
+            bool ex_hit = false;
+            for (int z = 0; z < nex; ++z) ex_hit |= ex[z] == c;
+            if (!ex_hit) {
+                bv = k;
+                bi = ik;
+            }
+        }
+    });
+    block_argmin(bv, bi, sv, si);
+    if (bi < 0) return;          // nothing valid in the row
+    if (bi & VBIT) {             // a value leads: it is the row's first minimum
+        bi &= ~VBIT;
+        return;
+    }
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf);
+}
+
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
-__global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
+__global__ __launch_bounds__(1024) void row_argmin_tri_kernel(float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                                              const int32_t *__restrict__ asz, const int32_t *__restrict__ msz,
                                                              const int32_t *__restrict__ mcid, int max_size, int64_t nrows,
-                                                             float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+                                                             float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -475,9 +735,8 @@ __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(const float *__res
             bi = -1;
         } else {
             const int noex[1] = {-1};
-            scan_row_m(Dtri + rowoff[r], r, msz, mcid, (int)r, my, max_size, noex, 0, bv, bi);
+            scan_row_min(Dtri + rowoff[r], r, msz, mcid, (int)r, my, max_size, noex, 0, bv, bi, sv, si, rf);
         }
-        block_argmin(bv, bi, sv, si);
         if (threadIdx.x == 0) {
             rowmin[r] = bv;
             rownn[r] = bi;
@@ -572,6 +831,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         st->B.blk_next = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
+        for (int j = 0; j < 8; ++j) st->B.rf_stat[j] = 0;
     }
 }
 
@@ -625,10 +885,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // bound is lexicographically >= it, hence so is its true minimum: the pick equals the reference's full scan
 // (clustering.go:119-133), ties included.
 __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
-                                               int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
+                                               int32_t *__restrict__ rownn, float *__restrict__ Dtri,
                                                const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                                const int32_t *__restrict__ mcid, int max_size, ward_state *__restrict__ st,
-                                               float *sv, int *si, int *sh)
+                                               float *sv, int *si, int *sh, const wrefine &rf)
 {
     if (st->done) return;
     const int t = st->t;
@@ -674,9 +934,8 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
         int ri;
         {
             const int noex[1] = {-1};
-            scan_row_m(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri);
+            scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf);
         }
-        block_argmin(rv, ri, sv, si);
         if (threadIdx.x == 0) {
             rowmin[bi] = rv;
             rownn[bi] = ri;
@@ -692,15 +951,15 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
 
 // preselect(0): before the first merge there is no update to run beside.
 __global__ __launch_bounds__(1024) void ward_presel_kernel(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin,
-                                                          int32_t *__restrict__ rownn, const float *__restrict__ Dtri,
+                                                          int32_t *__restrict__ rownn, float *__restrict__ Dtri,
                                                           const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                                           const int32_t *__restrict__ mcid, int max_size,
-                                                          ward_state *__restrict__ st)
+                                                          ward_state *__restrict__ st, const wrefine rf)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int sh[2];
-    ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
+    ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf);
 }
 
 // finish(t), ONE workgroup: (a) publish the row cache of the cluster created by merge t-1 (its minimum was reduced by
@@ -850,7 +1109,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
                                                                const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                                                float *__restrict__ Dtri, ward_state *__restrict__ st,
                                                                int max_size, int64_t n, float *__restrict__ rowmin,
-                                                               int32_t *__restrict__ rownn_w)
+                                                               int32_t *__restrict__ rownn_w, const wrefine rf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 upd_lds[]; // [2][UPD_SG][64] p ring, then the new centroid image
     float4 (*ring)[UPD_SG][64] = reinterpret_cast<float4 (*)[UPD_SG][64]>(upd_lds);
@@ -858,7 +1117,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_exact_kernel(int d, i
         float *sv = reinterpret_cast<float *>(upd_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
         int *sh = si + 16;
-        ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
+        ward_preselect(n, asz, rowmin, rownn_w, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -1016,7 +1275,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ward_update_lw_kernel(const int32
     __shared__ int sh[2];
     __shared__ unsigned long long skey[UPD_THREADS / 64];
     if (blockIdx.x == gridDim.x - 1) {
-        ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
+        ward_preselect(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, wrefine{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f}); // FAST mode: the MFMA matrix holds (approximate) values
         return;
     }
     if (st->done || !st->cur_valid) return;
@@ -1128,7 +1387,7 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                  const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
-                                 int max_size, ward_state *__restrict__ st, float *sv, int *si)
+                                 int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine &rf)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ int lcnt;
@@ -1144,9 +1403,9 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     }
     if (threadIdx.x == 0) lcnt = 0;
     __syncthreads();
-    int ex[2 * WB_K];
+    int ex[2 * WB_K]; // wave-uniform: kept in scalar registers (every row-cache entry is tested against all of them)
 #pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
+    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = __builtin_amdgcn_readfirstlane(excl[z]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     // ---- phase A: one pass over this workgroup's slice (int4 groups of rownn / float4 groups of rowmin)
     const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32 / -1
@@ -1232,8 +1491,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         float rv = ICL_MAXF;
         int ri = -1;
         if (r >= 0) {
-            scan_row_m(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri);
-            block_argmin(rv, ri, sv, si);
+            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf);
         }
         if (threadIdx.x == 0) {
             st->B.spec_row[m * WB_R + wg] = r;
@@ -1250,7 +1508,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
 __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                      float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                      const int32_t *__restrict__ mcid, int max_size,
-                                     ward_state *__restrict__ st, float *sv, int *si, int *sh)
+                                     ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine &rf)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
@@ -1274,7 +1532,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     __syncthreads();
     int ex[2 * WB_K];
 #pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = excl[z];
+    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = __builtin_amdgcn_readfirstlane(excl[z]);
     // ---- the row caches were scanned by the spare workgroups (one slice each): merge their WB_R streams of WB_PA_KEYS entries
     const int epoch0 = st->B.epoch;
     if (wave == 0) {
@@ -1443,8 +1701,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        scan_row_m(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri);
-        block_argmin(rv, ri, sv, si); // ends with a barrier: cmd may be rewritten afterwards
+        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
                 if (ri < 0) {
@@ -1689,14 +1946,14 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                                                                       const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                                                       float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf);
         return;
     }
     if (blockIdx.x == WB_R) {
@@ -1705,7 +1962,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         int *sh = si + 16;
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -2007,11 +2264,13 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
     __shared__ int si[16];
     __shared__ int sh[8];
     if (blockIdx.x < WB_R) {
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si);
+        const wrefine norf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f}; // FAST mode: the MFMA matrix holds (approximate) values
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, norf);
         return;
     }
     if (blockIdx.x == WB_R) {
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh);
+        const wrefine norf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, norf);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -2148,7 +2407,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                                                                 int32_t *__restrict__ merges, float *__restrict__ Dtri,
                                                                 int64_t *__restrict__ rowoff, int32_t *__restrict__ mcol, int32_t *__restrict__ msz,
                                                                 int32_t *__restrict__ mcid, int64_t ld, int max_size, ward_state *__restrict__ st, int lw,
-                                                                int32_t *__restrict__ fdrec)
+                                                                int32_t *__restrict__ fdrec, const wrefine rf)
 {
     // fdrec: the express path's data phase runs in ward_finish_data_kernel (several workgroups) from the record written here
     // (nullptr -- FAST mode, or d % 4 != 0 -- never takes the express path's data phase)
@@ -2702,9 +2961,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             int ri;
             {
                 const int noex[1] = {-1};
-                scan_row_m(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri);
+                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf);
             }
-            block_argmin(rv, ri, sv, si);
             if (threadIdx.x == 0) {
                 rowmin[bi] = rv;
                 rownn[bi] = ri;
@@ -2843,7 +3101,10 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st};
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero};
+        w->nrm = nullptr;
+        w->colsum = nullptr;
+        w->zero = nullptr;
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         for (auto &sp : w->staged)
@@ -2886,6 +3147,10 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rownn, int32_t, w->M);
         WS_ALLOC(rowoff, int64_t, w->M + 1);
         WS_ALLOC(mcol, int32_t, w->M);
+        WS_ALLOC(nrm, float, n);
+        WS_ALLOC(colsum, double, dd);
+        WS_ALLOC(zero, char, 256);
+        ICL_HIP(ctx, hipMemsetAsync(w->zero, 0, 256, ctx->stream));
         WS_ALLOC(msz, int32_t, w->ld);
         WS_ALLOC(mcid, int32_t, w->ld);
         WS_ALLOC(Dtri, float, w->dtri_floats);
@@ -3163,9 +3428,28 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (own_hi < 0) own_hi = n;
     if (own_lo < 0 || own_lo > own_hi || own_hi > n || own_lo % DT_TILE || (own_hi % DT_TILE && own_hi != n))
         return icl_fail(ctx, ICL_ERR_ARG, "own rows [%lld, %lld) must be whole 128-row tile rows of [0, %lld)", (long long)own_lo, (long long)own_hi, (long long)n);
+    // Exact mode, the rows this call computes itself: by default PROVEN LOWER BOUNDS from the matrix cores, made exact on demand by
+    // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
+    // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
+    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
+    struct free_guard {
+        void *p = nullptr;
+        ~free_guard() { if (p) (void)hipFree(p); }
+    } g_ec;
+    const bool use_bound = !lw && own_hi > own_lo && d >= 1 && d <= 8192 && n < (1LL << 29) && (ctx->ward_dist == 2 || (ctx->ward_dist == 0 && n >= 4096));
     if (lw) {
         if (own_lo != 0 || own_hi != n) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "FAST mode builds the whole distance matrix on one GPU");
         ICL_TRY(icl_dist_mfma_launch(ctx, d_E, n, d, w->Dtri, w->rowoff, 0));
+    } else if (use_bound) {
+        const int K = (d + 31) / 32 * 32;
+        if (hipMalloc(&g_ec.p, (size_t)n * K * 4) != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "centred copy of E (%lld x %d floats)", (long long)n, K);
+        const double u = 5.9604644775390625e-08; // 2^-24
+        const double gD = K * u / (1.0 - K * u), gp = std::pow(1.0 + u, d + 2) - 1.0;
+        rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)),
+                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f};
+        ICL_TRY(icl_dist_center_launch(ctx, d_E, n, d, K, w->colsum, (float *)g_ec.p, w->nrm, ctx->stream));
+        ICL_TRY(icl_dist_bound_launch(ctx, (const float *)g_ec.p, w->nrm, w->zero, n, K, rf.ceps, rf.gam, w->Dtri, w->rowoff, own_lo / DT_TILE,
+                                      icl_ceil_div(own_hi, DT_TILE), ctx->stream));
     } else
         ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0, own_lo / DT_TILE, icl_ceil_div(own_hi, DT_TILE)));
     // rows computed elsewhere (other GPUs) arrived in the transport format -- spans of the packed lower triangle -- and are
@@ -3177,9 +3461,15 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     }
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
+        wrefine rf_init = rf;
+        rf_init.stat = rf.stat ? rf.stat + 4 : nullptr;
+        // the initial minima also make exact everything up to 4x the row's threshold (one parallel round per row).  Measured at 100 000
+        // ResNet embeddings: 5.3 M entries (0.11 % of the pairs) at margin 3, 5.4 M at 15, 323 M (6.5 %, distance stage 0.2 -> 1.4 s) at 63;
+        // the merge loop then still needs 8 213 rounds (1.4 per step, 8 652 entries) for rows whose near neighbours are all gone
+        rf_init.margin = 3.0f;
         const int blocks = (int)std::min<int64_t>(n, 256 * 64);
         hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, w->msz, w->mcid,
-                           max_size, n, w->rowmin, w->rownn);
+                           max_size, n, w->rowmin, w->rownn, rf_init);
         ICL_HIP(ctx, hipGetLastError());
     }
     ICL_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -3190,10 +3480,16 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const unsigned upd_blocks = (unsigned)(w->S / 64) + 2; // 64 slots per workgroup + preselect + compaction workgroups
     const int dqp = (int)upd_groups(d);
     const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16 + (size_t)2 * UPD_SG * 64 * 16; // new centroid image + p ring
-    if (upd_lds > 160 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
-    if (!w->upd_attr) { // per context, i.e. per device
-        (void)hipFuncSetAttribute((const void *)ward_update_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        w->upd_attr = true;
+    static const bool batch_env = [] {
+        const char *e = getenv("ICL_WARD_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    if (!batch_env && upd_lds > 64 * 1024 && w->upd_attr_bytes < upd_lds) { // one-merge-per-step pipeline only; per context, i.e. per device
+        hipFuncAttributes fa;
+        ICL_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)ward_update_exact_kernel));
+        if (upd_lds + fa.sharedSizeBytes > 160 * 1024) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "embedding dimension %d too large for the update kernel's LDS image", d);
+        ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds));
+        w->upd_attr_bytes = upd_lds;
     }
     auto finish = [&]() {
         hipLaunchKernelGGL(ward_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->slot_id,
@@ -3207,7 +3503,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             return;
         }
         hipLaunchKernelGGL(ward_update_exact_kernel, dim3(upd_blocks), dim3(UPD_THREADS), upd_lds, ctx->stream, d, dqp, w->S, w->CT, w->Crow,
-                           w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
+                           w->cnew, w->slot_id, w->asz, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, rf);
     };
     // one step: update(t) [with preselect(t+1) as one of its workgroups] -> finish(t+1)
     auto enqueue_step = [&](int64_t t, bool prof) {
@@ -3221,10 +3517,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     };
     const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
     constexpr int GRAPH_STEPS = 64;
-    static const bool batch_env = [] {
-        const char *e = getenv("ICL_WARD_BATCH");
-        return !(e && e[0] == '0');
-    }();
     const bool batched = batch_env; // both modes: exact centroid chains, or Lance-Williams rows (lw)
     ward_state hst;
     if (batched) {
@@ -3245,7 +3537,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, w->mcol, w->msz, w->mcid, w->ld, max_size,
-                               w->st, lw ? 1 : 0, fdrec);
+                               w->st, lw ? 1 : 0, fdrec, rf);
             if (fdrec) // the express step's data phase on several CUs, the pair-interleaved copy of the new centroids, the block counter reset
                 hipLaunchKernelGGL(ward_finish_data_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, WB_FD_THREADS)), dim3(WB_FD_THREADS), 0,
                                    ctx->stream, d, w->S, w->CT, w->Crow, w->cnew, w->cnewI, w->cn_stride, fdrec, w->st);
@@ -3261,7 +3553,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
             hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
-                               w->rowmin, w->rownn);
+                               w->rowmin, w->rownn, rf);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -3275,7 +3567,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         };
         finish_b(); // first batch: one pick by the plain lazy selection
         const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2))) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -3287,6 +3579,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
             w->graph_lw = lw ? 3 : 2;
+            w->graph_E = rf.E;
+            w->graph_ceps = rf.ceps;
         }
         ICL_HIP(ctx, hipHostMalloc(&gpin.p, 2 * sizeof(ward_state), hipHostMallocDefault));
         ward_state *hpin = (ward_state *)gpin.p; // two pinned snapshots
@@ -3317,12 +3611,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         if (rc_b != ICL_OK) return icl_fail(ctx, ICL_ERR_HIP, "batched merge loop: %s", hipGetErrorString(hipGetLastError()));
     } else {
     hipLaunchKernelGGL(ward_presel_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->Dtri, w->rowoff, w->msz, w->mcid,
-                       max_size, w->st); // merge 0 has no update in front of it
+                       max_size, w->st, rf); // merge 0 has no update in front of it
     finish();
     if (prof_update || T < 2 * GRAPH_STEPS) {
         for (int64_t t = 0; t < T; ++t) enqueue_step(t, prof_update);
     } else {
-        if (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (int)lw) {
+        if (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (int)lw || w->graph_E != rf.E || w->graph_ceps != rf.ceps) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -3334,6 +3628,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
             w->graph_lw = (int)lw;
+            w->graph_E = rf.E;
+            w->graph_ceps = rf.ceps;
         }
         for (int64_t t = 0; t < T; t += GRAPH_STEPS) ICL_HIP(ctx, hipGraphLaunch(w->graph_exec, ctx->stream));
     }
@@ -3355,6 +3651,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
                 hst.B.slow, hst.B.general);
+    if (batched && getenv("ICL_WARD_STATS") && rf.E)
+        fprintf(stderr, "[icl] distance bounds in the merge loop: %llu scans of singleton rows, %llu collecting passes, %llu evaluation rounds, %llu entries evaluated\n",
+                hst.B.rf_stat[0], hst.B.rf_stat[1], hst.B.rf_stat[2], hst.B.rf_stat[3]);
+    if (batched && getenv("ICL_WARD_STATS") && rf.E)
+        fprintf(stderr, "[icl] distance bounds, initial row minima: %llu rows, %llu evaluation rounds, %llu entries evaluated (%.2f %% of the pairs)\n",
+                hst.B.rf_stat[4], hst.B.rf_stat[6], hst.B.rf_stat[7], 100.0 * (double)hst.B.rf_stat[7] / (0.5 * (double)n * (double)(n - 1)));
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
 #ifdef ICL_WARD_TIMERS
@@ -3533,6 +3835,14 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
     if (!ctx->ward || ctx->ward->capN != n || ctx->ward->capD != d)
         return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: call icl_ward_prepare(n, d) and deposit the foreign rows first");
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, own_lo, own_hi);
+}
+
+extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
+{
+    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_BOUND) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->ward_dist = dist_mode;
+    return ICL_OK;
 }
 
 extern "C" int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,

@@ -79,7 +79,7 @@ def LoadPretrainedModelONNX(modelPath: str, device: int = 0):
 
 
 def PreprocessImage(imagePath: str):
-    """embeddings.go:46-116 -> (Mat, err): IMRead (baseline or progressive JPEG / binary PPM, decoded bit-identically to libjpeg-turbo) ->
+    """embeddings.go:46-116 -> (Mat, err): IMRead (baseline or progressive JPEG decoded bit-identically to libjpeg-turbo, PNG bit-identically to Pillow / libpng, binary PPM) ->
     Resize 224x224 INTER_LINEAR -> RGB; Mat.Blob() gives the 1x3x224x224 fp32 blob scaled by 1/255."""
     try:
         rgb = _lib.load_image_224(imagePath)  # IMRead (+ EXIF orientation) -> cv::resize -> RGB; icl_preprocess_file = this + Blob()

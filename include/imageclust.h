@@ -79,7 +79,7 @@ int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes); /* host only, 
  * (a helper thread owned by the call) overlaps the forward passes of the current one.  The _dev variant takes device pointers. */
 int icl_embed_u8(icl_ctx *ctx, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
 int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head, int prec, float *d_out);
-/* One image file (baseline or progressive Huffman JPEG, or binary PPM "P6"): decode, bilinear resize to 224x224
+/* One image file (baseline or progressive Huffman JPEG, non-interlaced PNG, or binary PPM "P6"): decode, bilinear resize to 224x224
  * (embeddings.go:69), then as icl_embed_u8 with n = 1, fp32. */
 int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
 /* icl_embed_file is what GetImageEmbedding(appCtx, path) binds to, and workflow.go:156-175 calls that from one goroutine per
@@ -88,7 +88,7 @@ int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
  * result bit for bit) or ICL_PREC_BF16.  window_us = 0 disables waiting (a lone caller runs at once). */
 int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch);
 int icl_file_batch_stats(icl_ctx *ctx, int64_t *batches, int64_t *images); /* forward passes run / images served by icl_embed_file */
-/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, or binary PPM) to interleaved RGB.
+/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, non-interlaced PNG, or binary PPM) to interleaved RGB.
  * With rgb == NULL only *w / *h are returned.  cap_bytes must be >= w*h*3. */
 int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h);
 /* decode + cv::resize(INTER_LINEAR)-compatible resize to 224x224 (embeddings.go:50,69): out is 224*224*3 u8 RGB. */
@@ -183,6 +183,12 @@ int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_
 enum { ICL_FUSE_OVERLAP = 1 };
 int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update, int flags,
                           float *d_E, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
+/* How the exact mode builds ComputeInitialDistanceMatrix (clustering.go:61-73).  ICL_DIST_EXACT: every value by the exact
+ * vector-ALU kernel (3 D unfused fp32 ops per pair).  ICL_DIST_BOUND: proven lower bounds from an f32 GEMM on the matrix cores,
+ * each entry evaluated exactly (the reference's own expression) only when a row scan finds it near the row's minimum -- the same
+ * cluster ids, member order, merge log and merge values, bit for bit.  ICL_DIST_AUTO (default): bounds for n >= 4096. */
+enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2 };
+int icl_set_ward_options(icl_ctx *ctx, int dist_mode);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
  * cluster, creation id of the lower-position one); returns the number of merges performed. */
 int64_t icl_last_merges(icl_ctx *ctx, int32_t *pairs, int64_t cap_pairs);

@@ -252,6 +252,41 @@ def test_every_small_case_against_both_oracles(ctx, name, E, mn, mx):
     same_as_fast_oracle(ctx, E, mn, mx)
 
 
+def test_distance_bounds_mode_on_every_small_case(ctx):
+    """ICL_DIST_BOUND forced on the small suite (auto mode only uses it from n = 4096): the initial matrix holds proven lower
+    bounds from the f32 MFMA GEMM and entries are evaluated exactly on demand by the row scans -- ties, duplicates, NaN / Inf,
+    tight constraints, D not a multiple of 4 or 32, D > 2048.  Ids, member order, merge log and every merge value against both oracles."""
+    ctx.set_ward_options(2)
+    try:
+        for name, E, mn, mx in WC.small_cases():
+            try:
+                same_as_oracle(ctx, E, mn, mx)
+                same_as_fast_oracle(ctx, E, mn, mx)
+            except AssertionError as e:
+                raise AssertionError("%s: %s" % (name, e))
+    finally:
+        ctx.set_ward_options(0)
+
+
+def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
+    """Bounds vs exact initial distances on inputs built to crowd the band: N = 6000 points that are tiny perturbations of 300
+    centres (pairs inside a group differ in the last bits), D = 96, and an integer grid with thousands of exact ties.  The two
+    modes must give the same merge log, values, ids and member order."""
+    rng = np.random.default_rng(8)
+    cen = rng.standard_normal((300, 96)).astype(np.float32)
+    E1 = (cen[rng.integers(0, 300, 6000)] * (1 + 1e-6 * rng.standard_normal((6000, 1)))).astype(np.float32)
+    for E, mn, mx in [(E1, 5, 50), (WC.ties(5000, 5, 9, levels=6), 2, 30)]:
+        res = []
+        for mode in (1, 2):
+            ctx.set_ward_options(mode)
+            cid, rank, nc = ctx.cluster(E, mn, mx)
+            res.append((cid.copy(), rank.copy(), nc, ctx.last_merges().copy(), ctx.last_merge_values().copy()))
+        ctx.set_ward_options(0)
+        a, b = res
+        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
+
+
 def test_large_n_creation_ids_past_40960(ctx):
     """N=24 000, D=16, min=5 max=50: 21 360 merges, creation ids up to 45 359 (rows and columns of the matrix recycled ~21 000 times).  The batched
     update's spare workgroups once dropped rows >= 40 960 silently (16-iteration hit mask); ids, member order, the merge
@@ -331,7 +366,7 @@ def test_config2_full_size_two_pipelines_agree_100k(ctx):
 
     args = (100000, 2048, 20250218, 5, 50)
     mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
-    env = dict(os.environ, ICL_WARD_BATCH="0")
+    env = dict(os.environ, ICL_WARD_BATCH="0", ICL_CHILD_DIST="1")  # the witness also builds every initial distance with the exact kernel
     p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), *map(str, args)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     other = json.loads(p.stdout.strip().splitlines()[-1])

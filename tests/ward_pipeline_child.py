@@ -32,6 +32,7 @@ def digests(ctx, E, mn, mx):
 
 if __name__ == "__main__":
     ctx = _lib.Context(0)
+    ctx.set_ward_options(int(os.environ.get("ICL_CHILD_DIST", "0")))  # 1: every initial distance by the exact kernel (include/imageclust.h ICL_DIST_*)
     if sys.argv[1] == "--npy":  # E from a file, results into an npz: small cases the parent compares with the oracle
         E = np.load(sys.argv[2])
         mn, mx = int(sys.argv[4]), int(sys.argv[5])
