@@ -596,8 +596,9 @@ __device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float 
 
 __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine rf)
+                                             const wrefine rf, float tv0, int ti0, float thr0)
 {
+    // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
     __shared__ int ref_cnt;
     __shared__ int ref_col[WB_REF_CAP];
     auto excluded = [&](int c) { // (read from the caller's list -- LDS -- on the rare candidates only: no registers held across the row)
@@ -606,11 +607,11 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         return hit;
     };
     const float nme = rf.nrm[my_id];
-    if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
-    for (;;) {
+    for (bool first = true;; first = false) {
         // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
-        float tv = ICL_MAXF, ub = ICL_MAXF, lmin = ICL_MAXF;
-        int ti = -1;
+        float tv = first ? tv0 : ICL_MAXF, ub = ICL_MAXF, lmin = first ? 0.0f : ICL_MAXF;
+        int ti = first ? ti0 : -1;
+        if (!first)
         ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int) {
             if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
             if (wflagged(v)) {
@@ -627,8 +628,8 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
                 }
             }
         });
-        block_min3(tv, ti, ub, lmin, sv, si);
-        const float thr = tv < ub ? tv : ub; // the row's minimum is <= thr
+        if (!first) block_min3(tv, ti, ub, lmin, sv, si);
+        const float thr = first ? thr0 : (tv < ub ? tv : ub); // the row's minimum is <= thr
         // lmin == MaxFloat32: no valid flagged entry (bounds are finite, far below MaxFloat32).  lmin > thr: every flagged entry
         // is strictly above the minimum.  Either way the best value stands.
         if (lmin == ICL_MAXF || lmin > thr) {
@@ -678,11 +679,46 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
     }
 }
 
+// Two lexicographic (value, index) minima over the workgroup in one pass through LDS
+__device__ __forceinline__ void block_argmin2(float &v0, int &i0, float &v1, int &i1, float *sv, int *si)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_down(v0, off, 64), b = __shfl_down(v1, off, 64);
+        const int ai = __shfl_down(i0, off, 64), bi = __shfl_down(i1, off, 64);
+        argmin_combine(v0, i0, a, ai);
+        argmin_combine(v1, i1, b, bi);
+    }
+    __shared__ float v2[16];
+    __shared__ int i2[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sv[wid] = v0;
+        si[wid] = i0;
+        v2[wid] = v1;
+        i2[wid] = i1;
+    }
+    __syncthreads();
+    float a = sv[0], b = v2[0];
+    int ai = si[0], bi = i2[0];
+    for (int w = 1; w < nw; ++w) { // every thread reduces the <= 16 wave results itself
+        argmin_combine(a, ai, sv[w], si[w]);
+        argmin_combine(b, bi, v2[w], i2[w]);
+    }
+    v0 = a;
+    i0 = ai;
+    v1 = b;
+    i1 = bi;
+    __syncthreads(); // the scratch may be rewritten
+}
+
 // The row scan of every merge-loop kernel: result reduced over the workgroup.
-// Rows that may hold bounds (singleton rows while rf.E is set) first get ONE optimistic pass that costs what scan_row_m costs:
-// a flagged entry competes with its lower bound |v| and wins ties against values.  If a VALUE comes out on top, every bound is
-// strictly above it, so every flagged entry's true value is too: the value is the row's first minimum, exactly as the full
-// procedure would find it.  Only when a bound comes out on top does scan_row_refine run.
+// Rows that may hold bounds (singleton rows while rf.E is set): ONE pass finds the first minimum among VALUES and the smallest
+// lower bound among flagged entries.  If the best value is strictly below every bound, every flagged entry's true value is
+// above it too: the value is the row's first minimum (95 % of the merge loop's scans end here, at the cost of scan_row_m).
+// Otherwise the threshold is min(best value, upper bound of the entry with the smallest lower bound) -- the row's minimum
+// cannot exceed either -- and the flagged entries at or below it are evaluated (scan_row_refine's collecting pass and round;
+// more than WB_REF_CAP of them: its full loop).
 __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
                                              const wrefine &rf)
@@ -692,30 +728,38 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         block_argmin(bv, bi, sv, si);
         return;
     }
-    // index key: a flagged entry keeps its creation id (< n < 2^29: bounds are only built below that size), a value gets bit 30 set,
-    // so among equal keys a bound wins, then the smaller creation id
-    constexpr int VBIT = 1 << 30;
-    bv = ICL_MAXF;
-    bi = -1;
+    auto excluded = [&](int c) {
+        bool hit = false;
+        for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
+        return hit;
+    };
+    float tv = ICL_MAXF, lv = ICL_MAXF;
+    int ti = -1, lc = -1;
     ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int) {
-        const float k = fabsf(v);
-        const int ik = wflagged(v) ? c : (c | VBIT);
-        if (m > 0 && m + my_size <= max_size && c < my_id && (k < bv || (k == bv && ik < bi))) {
-            bool ex_hit = false;
-            for (int z = 0; z < nex; ++z) ex_hit |= ex[z] == c;
-            if (!ex_hit) {
-                bv = k;
-                bi = ik;
+        if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
+        if (wflagged(v)) {
+            const float L = fabsf(v);
+            if ((L < lv || (L == lv && c < lc)) && !excluded(c)) {
+                lv = L;
+                lc = c;
+            }
+        } else if (v < tv || (v == tv && c < ti)) {
+            if (!excluded(c)) {
+                tv = v;
+                ti = c;
             }
         }
     });
-    block_argmin(bv, bi, sv, si);
-    if (bi < 0) return;          // nothing valid in the row
-    if (bi & VBIT) {             // a value leads: it is the row's first minimum
-        bi &= ~VBIT;
+    block_argmin2(tv, ti, lv, lc, sv, si);
+    if (lc < 0 || lv > tv) { // no bound at or below the best value
+        bv = tv;
+        bi = ti;
         return;
     }
-    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf);
+    if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
+    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[lc], rf);
+    const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr);
 }
 
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
