@@ -30,6 +30,7 @@
 
 #include "icl_common.h"
 #include "mfma_tile.h"
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include <algorithm>
 #include <cmath>
@@ -122,6 +123,8 @@ struct icl_ward_ws {
     int64_t ld = 0;            // row pitch in floats (N rounded up to 64)
     float *nrm = nullptr;      // [capN] |E[r] - mu|^2 of the singletons: the scans' upper bounds of flagged entries (distance bounds)
     double *colsum = nullptr;  // [capD] column sums of E
+    float *mu = nullptr;       // [cn_stride] the centring vector (zero padded): bound body of the update kernel
+    size_t wxb_attr = 0;       // dynamic LDS the bound instantiation of the update kernel has been opted in for
     void *zero = nullptr;      // 256 zero bytes (LDS-DMA source of rows beyond n)
     int64_t dtri_floats = 0;
     std::vector<std::pair<std::pair<int64_t, int64_t>, float *>> staged; // foreign distance rows [lo, hi) in transport (packed) format, unpacked by the next cluster call
@@ -150,7 +153,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mu};
     for (auto &sp : w->staged)
         if (sp.second) (void)hipFree(sp.second);
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
@@ -483,13 +486,25 @@ struct wrefine {
                       // decides how much is made exact ahead of need.  The initial row minima use a generous margin (the evaluations
                       // of one round run in parallel, one per thread: ~10 us whether 3 or 1000), so that the merge loop's rescans --
                       // which sit on the update kernel's critical path -- find the near entries exact already
+    // rows of MERGED clusters (ward_update_bound body): bounds too when upd != 0.  nrm then has an entry per creation id.
+    int upd;
+    const float *Crow;       // [S][d] centroids by slot
+    const int32_t *id_slot;  // creation id -> slot
+    float ceps_m, gam_m;     // the constants of pairs with a merged member (distance_mfma.hip, "merged clusters")
 };
 __device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
-__device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf)
+// w2 = 2 fl(sa sb / (sa + sb)) (1 for two singletons); merged: the row belongs to a merged cluster
+__device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf, float w2 = 1.0f, bool merged = false)
 {
-    // R <= (T + E_ab)(1 + g'),  T - E_ab <= L (1 + 2 g')  (the store rounded L down by at most g' + 3e-7 relative):
-    // R <= (L (1 + 2 g') + 2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
-    return (L * (1.0f + 3.0f * rf.gam) + 2.0001f * rf.ceps * ns) * (1.0f + 2.0f * rf.gam);
+    // R <= (T + E_ab)(1 + g') w2,  w2 (T - E_ab) <= L (1 + 2 g')  (the store rounded L down by at most g' + 1e-6 relative):
+    // R <= (L (1 + 2 g') + 2 w2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
+    const float g = merged ? rf.gam_m : rf.gam, ce = merged ? rf.ceps_m : rf.ceps;
+    return (L * (1.0f + 3.0f * g) + 2.0001f * (w2 * ce) * ns) * (1.0f + 2.0f * g);
+}
+__device__ __forceinline__ float ward_w2(int sa, int sb)
+{
+    const float num = (float)((int64_t)sa * (int64_t)sb), den = (float)(sa + sb);
+    return 2.0f * (num / den);
 }
 // WardDistance of two SINGLETONS from their embeddings (clustering.go:136-157 with sizes 1, 1): sequential, unfused fp32
 __device__ __forceinline__ float ward_singleton_pair(const float *__restrict__ E, int d, int a, int b)
@@ -522,6 +537,45 @@ __device__ __forceinline__ float ward_singleton_pair(const float *__restrict__ E
     const float num = (float)((int64_t)1 * (int64_t)1); // :142
     const float den = (float)(1 + 1);                    // :143
     return (num / den) * s;                              // :144
+}
+
+// WardDistance of two clusters from their centroids (clustering.go:136-157): what the exact update kernels compute per entry
+__device__ __forceinline__ float ward_pair_value(const float *__restrict__ x, const float *__restrict__ y, int d, int sx, int sy)
+{
+    float s = 0.0f;
+    if ((d & 3) == 0) {
+        for (int k = 0; k < d; k += 4) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + k), yv = *reinterpret_cast<const float4 *>(y + k);
+            float df = xv.x - yv.x;
+            float p = df * df;
+            s = s + p;
+            df = xv.y - yv.y;
+            p = df * df;
+            s = s + p;
+            df = xv.z - yv.z;
+            p = df * df;
+            s = s + p;
+            df = xv.w - yv.w;
+            p = df * df;
+            s = s + p;
+        }
+    } else {
+        for (int k = 0; k < d; ++k) {
+            const float df = x[k] - y[k];
+            const float p = df * df;
+            s = s + p;
+        }
+    }
+    const float num = (float)((int64_t)sx * (int64_t)sy); // :142
+    const float den = (float)(sx + sy);                    // :143
+    return (num / den) * s;                                // :144
+}
+// the value behind a flagged entry of row my_id (size my_size; its centroid: my_cent, or looked up) against cluster c (size m)
+__device__ __forceinline__ float wpair_value(const wrefine &rf, int my_id, int my_size, const float *my_cent, int c, int m)
+{
+    if (my_id < rf.n) return ward_singleton_pair(rf.E, rf.d, my_id, c);
+    const float *y = my_cent ? my_cent : rf.Crow + (int64_t)rf.id_slot[my_id] * rf.d;
+    return ward_pair_value(rf.Crow + (int64_t)rf.id_slot[c] * rf.d, y, rf.d, m, my_size);
 }
 
 // visits columns [0, len) of a row: f(value, msz, mcid, column) with 4 x 16-byte loads of each stream in flight per lane
@@ -596,7 +650,7 @@ __device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float 
 
 __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine rf, float tv0, int ti0, float thr0)
+                                             const wrefine rf, float tv0, int ti0, float thr0, const float *my_cent)
 {
     // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
     __shared__ int ref_cnt;
@@ -607,6 +661,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         return hit;
     };
     const float nme = rf.nrm[my_id];
+    const bool mrow = my_id >= rf.n;
     for (bool first = true;; first = false) {
         // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
         float tv = first ? tv0 : ICL_MAXF, ub = ICL_MAXF, lmin = first ? 0.0f : ICL_MAXF;
@@ -618,7 +673,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
                 const float L = fabsf(v);
                 lmin = L < lmin ? L : lmin; // (an excluded entry counted here only costs an empty pass B)
                 if (L < tv && L < ub) { // its upper bound (>= L) can only matter below this thread's best value and best upper bound
-                    const float up = wupper(L, nme + rf.nrm[c], rf); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
+                    const float up = wupper(L, nme + rf.nrm[c], rf, mrow ? ward_w2(m, my_size) : 1.0f, mrow); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
                     if (up < ub && !excluded(c)) ub = up;
                 }
             } else if (v < tv || (v == tv && c < ti)) {
@@ -659,8 +714,8 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         int ri = -1;
         for (int q = threadIdx.x; q < m; q += blockDim.x) {
             const int col = ref_col[q];
-            const int c = mcid[col]; // == col: a valid flagged entry stands in a singleton's own column
-            const float val = ward_singleton_pair(rf.E, rf.d, my_id, c);
+            const int c = mcid[col];
+            const float val = wpair_value(rf, my_id, my_size, my_cent, c, msz[col]);
             row[col] = val; // a value from now on
             if (val < rv || (val == rv && c < ri)) {
                 rv = val;
@@ -721,9 +776,9 @@ __device__ __forceinline__ void block_argmin2(float &v0, int &i0, float &v1, int
 // more than WB_REF_CAP of them: its full loop).
 __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine &rf)
+                                             const wrefine &rf, const float *my_cent = nullptr)
 {
-    if (!(rf.E && my_id < rf.n)) {
+    if (!(rf.E && (my_id < rf.n || rf.upd))) {
         scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi);
         block_argmin(bv, bi, sv, si);
         return;
@@ -735,13 +790,13 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
     };
     float tv = ICL_MAXF, lv = ICL_MAXF;
     int ti = -1, lc = -1;
-    ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int) {
+    ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
         if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
         if (wflagged(v)) {
             const float L = fabsf(v);
-            if ((L < lv || (L == lv && c < lc)) && !excluded(c)) {
+            if (L < lv && !excluded(c)) { // (lc: the COLUMN of an entry with the smallest lower bound, any of them)
                 lv = L;
-                lc = c;
+                lc = col;
             }
         } else if (v < tv || (v == tv && c < ti)) {
             if (!excluded(c)) {
@@ -757,9 +812,10 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         return;
     }
     if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
-    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[lc], rf);
+    const bool mrow = my_id >= rf.n;
+    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf, mrow ? ward_w2(msz[lc], my_size) : 1.0f, mrow);
     const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
-    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr);
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, my_cent);
 }
 
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
@@ -1981,6 +2037,274 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
     static_assert(WB_K <= 16, "two chunks of 8 commits / picks");
 }
 
+// ---- BOUND body of the main workgroups (round 3) -------------------------------------------------------------------------
+// The exact rows cost 3 D unfused fp32 ops per (new cluster, live cluster) on the vector ALUs -- the update kernel ran at the
+// VALU issue rate, 2.5x above its HBM time.  With distance bounds in the matrix (distance_mfma.hip) the rows of the clusters
+// being created are written as PROVEN LOWER BOUNDS too: T = (n_x + n_c)/2 - x'.c' from v_mfma_f32_16x16x4_f32 (an fp32 fmaf
+// chain, bit for bit) over the mean-centred centroids, 16 new clusters x 16 live clusters per instruction.  The rows' minima
+// -- needed exactly by the finish kernel -- are then found by ward_newrow_min_kernel, which evaluates the reference's own
+// expression for the few entries whose bound sits in the band of the minimum; every other entry stays a flagged bound until a
+// later scan needs it (scan_row_min), and most never are.  Nothing the reference compares is taken from the matrix cores.
+//
+// Work split of a 64-cluster block: chain wave w = (column block cb = w & 3: clusters 16 cb .. 16 cb + 15) x (k half h = w >> 2:
+// G-steps 4h .. 4h+3 of every ring stage; a G-step = 4 k-groups = 16 k).  Lane l holds, per G-step, the float4 of k-group
+// 4G + (l >> 4) of live cluster (l & 15) [B operand] and of new cluster (l & 15) [A operand]: four MFMAs, one per component --
+// the k order inside the dot product is free, both operands use the same one.  The two halves' accumulators are added at the end
+// of the block (any summation order is inside the fma-chain bound gD).  The ring, the loaders, the cross-block prefetch and the
+// dirty-column handling are those of the exact body below; the centroid area of a stage holds [k-group][new cluster] float4.
+// |c'|^2 of the new clusters: the diagonal of their Gram matrix, by the same instruction on the same registers (column block 0's
+// two waves, in the workgroup's first block); every workgroup computes the same bits and stores them to nrm[] for later steps.
+struct wx_bound_args {
+    const float *mu;  // [>= 4 (dqp + WX_SG)] the centring vector of the distance bounds, zero padded
+    float *nrm;       // [n + merges] |centroid - mu|^2 by creation id
+};
+
+__device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, int64_t S, float *__restrict__ CT, const float *__restrict__ Crow,
+                                              const float *__restrict__ cnewK, int64_t cn_stride, const int32_t *__restrict__ slot_id,
+                                              const int32_t *__restrict__ asz, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
+                                              float *__restrict__ Dtri, ward_state *__restrict__ st, int max_size, int64_t n, const wrefine &rf,
+                                              const wx_bound_args &ba)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    if (done || nb <= 0) return;
+    const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
+    __shared__ int pa[WB_K], pb[WB_K], psc[WB_K];
+    __shared__ int64_t ro_l[WB_K];
+    __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_mx[2][64], nx_dirty[2][64];
+    __shared__ float4 part[4][64];   // the accumulators of the upper k half, by column block
+    __shared__ float nrc_p[2][WB_K]; // |c'_j|^2 of the new clusters: the two k halves
+    if (threadIdx.x < WB_K) {
+        pa[threadIdx.x] = st->B.a[threadIdx.x];
+        pb[threadIdx.x] = st->B.b[threadIdx.x];
+        psc[threadIdx.x] = st->B.sa[threadIdx.x] + st->B.sb[threadIdx.x];
+        ro_l[threadIdx.x] = (int)threadIdx.x < nb ? rowoff[n + t + threadIdx.x] : 0;
+    }
+    const int nstage = (dqp + WX_SG - 1) / WX_SG;
+    float4 *mu_l = wb_lds + WX_R * WX_STAGE_F4; // the centring vector, by k-group
+    for (int g = threadIdx.x; g < nstage * WX_SG; g += WX_THREADS) mu_l[g] = reinterpret_cast<const float4 *>(ba.mu)[g];
+    __syncthreads();
+    const int nmain = (int)gridDim.x - (WB_R + 2);
+    int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_mx = 0, pf_dirty = 0; // chain wave 0 only
+    auto pf_advance = [&](const int upto, const int par) { // (the exact body's prefetch of the next block's state: see there)
+        if (pf_done < 1 && upto >= 1) {
+            pf_raw = lane == 0 ? nmain + atomicAdd(&st->B.blk_next, 1) : 0;
+            pf_done = 1;
+        }
+        if (pf_done < 2 && upto >= 2) {
+            int r = pf_raw;
+            asm volatile("" : "+v"(r));
+            pf_blk = __builtin_amdgcn_readfirstlane(r);
+            const bool on = (int64_t)pf_blk * 64 < nlive;
+            const int sl = pf_blk * 64 + lane;
+            pf_dirty = 0;
+            const int nd = on ? dirty_n0 : 0;
+            for (int z = 0; z < nd; ++z) pf_dirty |= __builtin_amdgcn_readlane(dirty_s0, z) == sl;
+            pf_xr = on ? slot_id[sl] : -1;
+            pf_done = 2;
+        }
+        if (pf_done < 3 && upto >= 3) {
+            pf_x = ((int64_t)pf_blk * 64 + lane < nlive) ? pf_xr : -1;
+            pf_sx = pf_x >= 0 ? asz[pf_x] : 0;
+            pf_mx = pf_x >= 0 ? mcol[pf_x] : 0;
+            pf_done = 3;
+        }
+        if (pf_done < 4 && upto >= 4) {
+            if (lane == 0) nx_blk[par] = pf_blk;
+            nx_x[par][lane] = pf_x;
+            nx_sx[par][lane] = pf_sx;
+            nx_mx[par][lane] = pf_mx;
+            nx_dirty[par][lane] = pf_dirty;
+            pf_done = 4;
+        }
+    };
+    if (wave == 0) {
+        pf_raw = (int)blockIdx.x - (WB_R + 2);
+        pf_done = 1;
+        pf_advance(4, 0);
+    }
+    int rp = 0;
+    bool pre = false;
+    bool gram_done = false; // the new clusters' norms are in nrc_p (computed in this workgroup's first computed block)
+    const bool loader = wave >= WX_CW;
+    const int pj = wave - WX_CW;
+    const int cb = wave & 3, hk = (wave >> 2) & 1; // chain waves: column block, k half
+    const int lc = lane & 15, lq = lane >> 4;
+    const unsigned ring_base = lds_addr_of(wb_lds);
+    const int dq_real = d >> 2;
+    for (int blk_it = 0;; ++blk_it) {
+        const int par = blk_it & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int64_t mblk = __builtin_amdgcn_readfirstlane(nx_blk[par]);
+        rp = __builtin_amdgcn_readfirstlane(rp);
+        pf_done = 0;
+        if (mblk < 0 || mblk * 64 >= nlive) break;
+        const int64_t slot = mblk * 64 + lane;
+        const bool dirty_lane = nx_dirty[par][lane] != 0;
+        const bool any_dirty = __any(dirty_lane);
+        const char *ctb = reinterpret_cast<const char *>(CT);
+        const int64_t row_bytes = S * 16;
+        // new clusters' pieces: the stage's centroid area is [k-group][new cluster] float4; piece q holds k-groups 4q .. 4q+3:
+        // lane l fetches k-group 4q + l/16 of new cluster l%16 (lands lane-linear = at (4q + l/16) * 16 + l%16)
+        auto csrc_of = [&](int q, int stage) -> const char * {
+            return reinterpret_cast<const char *>(cnewK) + ((int64_t)lc * cn_stride + ((int64_t)stage * WX_SG + 4 * q + lq) * 4) * 4;
+        };
+        auto issue = [&](int stage, int phase, int64_t slot_l, bool dirty_l) {
+            const int g0 = stage * WX_SG + pj * WX_XOPS;
+            const unsigned sbase = ring_base + (unsigned)(((phase + stage) % WX_R) * WX_STAGE_F4 * 16);
+#pragma unroll
+            for (int q = 0; q < WX_XOPS; ++q) {
+                const int g = g0 + q;
+                const char *src = ctb + (int64_t)g * row_bytes + slot_l * 16;
+                if (dirty_l && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot_l * d + (int64_t)g * 4) * 4;
+                glds16_asm(src, sbase + (unsigned)((pj * WX_XOPS + q) * 1024));
+            }
+#pragma unroll
+            for (int q = 0; q < WX_COPS; ++q)
+                glds16_asm(csrc_of(pj * WX_COPS + q, stage), sbase + (unsigned)(WX_SG * 1024 + (pj * WX_COPS + q) * 1024));
+        };
+        const bool xblk = nstage >= 8;
+        const int iD = xblk ? (3 * nstage) / 4 - 1 : nstage - 1;
+        if (loader && !pre)
+            for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i, rp, slot, dirty_lane);
+        // which rows does this lane's cluster (lane = slot of the block) take part in?  Every wave computes the same masks.
+        const int x = nx_x[par][lane], sx = nx_sx[par][lane];
+        unsigned okmask = 0;
+        {
+            bool alive = x >= 0 && sx > 0;
+#pragma unroll
+            for (int j = 0; j < WB_K; ++j) {
+                if (j < nb) {
+                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
+                }
+            }
+        }
+        if (!__any(okmask != 0)) {
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave == 0) pf_advance(4, par ^ 1);
+            rp = (rp + (WX_R - 1 < nstage ? WX_R - 1 : nstage)) % WX_R;
+            pre = false;
+            unsigned long long dm = __ballot(dirty_lane);
+            while (dm) {
+                const int l = __ffsll((long long)dm) - 1;
+                dm &= dm - 1;
+                const int64_t sl = mblk * 64 + l;
+                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
+                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
+            }
+            continue;
+        }
+        // this lane's column in the epilogue: cluster 16 cb + lc of the block (chain waves of the lower k half)
+        const int ex_ = nx_x[par][cb * 16 + lc];
+        float nrm_x = 0.0f;
+        if (!loader && hk == 0 && ex_ >= 0) nrm_x = ba.nrm[ex_]; // (in flight during the whole block)
+        const bool gram = !loader && cb == 0 && !gram_done;
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0, gr0 = acc0, gr1 = acc0;
+        auto consume = [&](int stage) {
+            const float4 *sb_ = wb_lds + ((rp + stage) % WX_R) * WX_STAGE_F4;
+            const float4 *xr = sb_ + cb * 16 + lc;
+            const float4 *ar = sb_ + WX_SG * 64 + lc;
+            const float4 *mr = mu_l + stage * WX_SG;
+#pragma unroll
+            for (int gg = 0; gg < WX_SG / 8; ++gg) {
+                const int g = 4 * (hk * (WX_SG / 8) + gg) + lq; // this lane's k-group of the stage
+                const float4 xv = xr[g * 64], av = ar[g * 16], mv = mr[g];
+                const float x0 = xv.x - mv.x, x1 = xv.y - mv.y, x2 = xv.z - mv.z, x3 = xv.w - mv.w; // fl(x - mu): the centred operands
+                const float a0 = av.x - mv.x, a1 = av.y - mv.y, a2 = av.z - mv.z, a3 = av.w - mv.w;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, x2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, x3, acc1, 0, 0, 0);
+                if (gram) {
+                    gr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, gr0, 0, 0, 0);
+                    gr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, gr1, 0, 0, 0);
+                    gr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, a2, gr0, 0, 0, 0);
+                    gr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, a3, gr1, 0, 0, 0);
+                }
+            }
+        };
+        int nxt_blk = -1;
+        bool nxt_on = false, nxt_dirty = false;
+        for (int i = 0; i < nstage; ++i) {
+            if (loader) {
+                if (i + WX_R - 2 < nstage || nxt_on)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * WX_OPS) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (wave == 0) pf_advance(i == 0 ? 1 : i == (nstage >> 2) ? 2 : i == (nstage >> 1) ? 3 : i == iD ? 4 : 0, par ^ 1);
+            if (xblk && i == iD + 1) {
+                nxt_blk = __builtin_amdgcn_readfirstlane(nx_blk[par ^ 1]);
+                nxt_on = (int64_t)nxt_blk * 64 < nlive;
+                nxt_dirty = nxt_on && nx_dirty[par ^ 1][lane] != 0;
+            }
+            if (loader) {
+                if (any_dirty && i * WX_SG >= 2 * WB_SG) {
+                    const float4 *xr = wb_lds + ((rp + i) % WX_R) * WX_STAGE_F4 + lane;
+#pragma unroll
+                    for (int q = 0; q < WX_XOPS; ++q) {
+                        const int g = i * WX_SG + pj * WX_XOPS + q;
+                        if (dirty_lane && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot)) = xr[(pj * WX_XOPS + q) * 64];
+                    }
+                }
+                if (i + WX_R - 1 < nstage)
+                    issue(i + WX_R - 1, rp, slot, dirty_lane);
+                else if (nxt_on)
+                    issue(i + WX_R - 1 - nstage, rp + nstage, (int64_t)nxt_blk * 64 + lane, nxt_dirty);
+            } else {
+                consume(i);
+            }
+        }
+        if (wave == 0) pf_advance(4, par ^ 1);
+        rp = (rp + nstage) % WX_R;
+        pre = nxt_on;
+        // ---- the two k halves meet: the upper half's sums (and the norms' halves) go through LDS
+        f32x4 acc = acc0 + acc1;
+        if (!loader && hk == 1) part[cb][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (gram) {
+            const f32x4 gr = gr0 + gr1;
+            const int v = lc - 4 * lq; // the diagonal element of this lane's column, if it holds it: row 4 lq + v == lc
+            if (v >= 0 && v < 4) nrc_p[hk][lc] = v == 0 ? gr[0] : v == 1 ? gr[1] : v == 2 ? gr[2] : gr[3];
+        }
+        gram_done = true;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (loader || hk != 0) continue;
+        if (gram && lane < nb) ba.nrm[n + t + lane] = nrc_p[0][lane] + nrc_p[1][lane]; // (every workgroup stores the same bits)
+        {
+            const float4 o = part[cb][lane];
+            acc[0] += o.x;
+            acc[1] += o.y;
+            acc[2] += o.z;
+            acc[3] += o.w;
+        }
+        const unsigned okm = (unsigned)__shfl((int)okmask, cb * 16 + lc, 64);
+        const int sxe = nx_sx[par][cb * 16 + lc];
+        const int64_t mxe = nx_mx[par][cb * 16 + lc];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int j = 4 * lq + v; // the new cluster c_j
+            if (j < nb && ((okm >> j) & 1u)) {
+                const int sc = psc[j];
+                const float ns = nrm_x + (nrc_p[0][j] + nrc_p[1][j]);
+                const float T = 0.5f * ns - acc[v];
+                const float num = (float)((int64_t)sxe * (int64_t)sc), den = (float)(sxe + sc);
+                // 2 w (T - E)(1 - g'), pushed down against the roundings of this expression itself (distance_mfma.hip, "merged clusters")
+                float L = (T - rf.ceps_m * ns) * (1.0f - rf.gam_m);
+                L = (2.0f * (num / den)) * L;
+                L = L * (1.0f - 6e-7f);
+                L = (L > 1e-30f && ns < 1e37f) ? L : 0.0f; // subnormal range / overflowing norms (also NaN): no claim
+                Dtri[ro_l[j] + mxe] = __uint_as_float(__float_as_uint(L) | 0x80000000u);
+            }
+        }
+    } // block loop
+}
+
+template <bool BOUND>
 __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       const float *__restrict__ cnewI, int64_t cn_stride,
@@ -1990,9 +2314,14 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                                                                       const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                                                       float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf,
+                                                                      const wx_bound_args ba)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
+    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4 (+ the centring vector: bound body)
+    if (BOUND && blockIdx.x >= WB_R + 2) { // main workgroups of the bound mode; the virtual slots' few rows stay exact (body below)
+        wx_main_bound(wb_lds, d, dqp, S, CT, Crow, cnewK, cn_stride, slot_id, asz, rowoff, mcol, Dtri, st, max_size, n, rf, ba);
+        return;
+    }
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
@@ -2283,6 +2612,55 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
     } // block loop
+}
+
+// Bound mode, after the update: the minima of the rows just written (all bounds), one workgroup per new cluster c_j.
+//   ckey[j]:  first minimum over the clusters alive at c_j's time (members of LATER picks included) -- what the validation needs
+//   ckey2[j]: ... over the clusters that survive the whole batch -- the row's cache after a full commit
+// The batch is not committed yet: the columns still carry the names and sizes of the clusters before it, so the members of the
+// picks up to j (gone at c_j's time; the columns of a_0..a_{j-1} hold the virtual-slot entries D(c_j, c_i), whose keys the virtual
+// workgroup has already merged in) are excluded by name.  The second scan only runs when the first minimum is a later pick's member.
+__global__ __launch_bounds__(1024) void ward_newrow_min_kernel(int64_t n, const float *__restrict__ cnewK, int64_t cn_stride,
+                                                              const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
+                                                              const int32_t *__restrict__ mcid, float *__restrict__ Dtri, ward_state *__restrict__ st,
+                                                              int max_size, const wrefine rf)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int ex[2 * WB_K];
+    const int j = blockIdx.x;
+    if (st->done) return;
+    const int nb = st->B.nb, t = st->t;
+    if (j >= nb) return;
+    if (threadIdx.x < 2 * WB_K) {
+        const int q = threadIdx.x >> 1;
+        ex[threadIdx.x] = q < nb ? ((threadIdx.x & 1) ? st->B.b[q] : st->B.a[q]) : -1;
+    }
+    __syncthreads();
+    const int my_id = (int)(n + t + j), my_size = st->B.sa[j] + st->B.sb[j];
+    float *row = Dtri + rowoff[my_id];
+    const float *cent = cnewK + (int64_t)j * cn_stride;
+    float v1, v2;
+    int i1, i2;
+    scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * (j + 1), v1, i1, sv, si, rf, cent);
+    bool later = false;
+    for (int z = 2 * (j + 1); z < 2 * nb; ++z) later |= i1 >= 0 && ex[z] == i1;
+    v2 = v1;
+    i2 = i1;
+    if (later) scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * nb, v2, i2, sv, si, rf, cent);
+    if (threadIdx.x == 0) {
+        if (i1 >= 0 && v1 < ICL_MAXF) atomicMin(&st->B.ckey[j], ((unsigned long long)__float_as_uint(v1) << 32) | (unsigned)i1);
+        if (i2 >= 0 && v2 < ICL_MAXF) atomicMin(&st->B.ckey2[j], ((unsigned long long)__float_as_uint(v2) << 32) | (unsigned)i2);
+    }
+}
+
+// the centring vector of the distance bounds, exactly as dist_center_kernel forms it (distance_mfma.hip); mu is zero beyond d
+__global__ void ward_mu_kernel(const double *__restrict__ colsum, int64_t n, int d, float *__restrict__ mu)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d) return;
+    const double inv_n = 1.0 / (double)n;
+    mu[k] = (float)(colsum[k] * inv_n);
 }
 
 // FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
@@ -3145,7 +3523,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero};
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mu};
+        w->mu = nullptr;
         w->nrm = nullptr;
         w->colsum = nullptr;
         w->zero = nullptr;
@@ -3191,7 +3570,9 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rownn, int32_t, w->M);
         WS_ALLOC(rowoff, int64_t, w->M + 1);
         WS_ALLOC(mcol, int32_t, w->M);
-        WS_ALLOC(nrm, float, n);
+        WS_ALLOC(nrm, float, w->M); // by creation id (merged clusters: written by the update kernel's bound body)
+        ICL_HIP(ctx, hipMemsetAsync(w->nrm, 0, (size_t)w->M * sizeof(float), ctx->stream));
+        WS_ALLOC(mu, float, w->cn_stride);
         WS_ALLOC(colsum, double, dd);
         WS_ALLOC(zero, char, 256);
         ICL_HIP(ctx, hipMemsetAsync(w->zero, 0, 256, ctx->stream));
@@ -3475,12 +3856,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // Exact mode, the rows this call computes itself: by default PROVEN LOWER BOUNDS from the matrix cores, made exact on demand by
     // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
     // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
-    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
+    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f};
     struct free_guard {
         void *p = nullptr;
         ~free_guard() { if (p) (void)hipFree(p); }
     } g_ec;
-    const bool use_bound = !lw && own_hi > own_lo && d >= 1 && d <= 8192 && n < (1LL << 29) && (ctx->ward_dist == 2 || (ctx->ward_dist == 0 && n >= 4096));
+    const bool use_bound = !lw && own_hi > own_lo && d >= 1 && d <= 8192 && n < (1LL << 29) && (ctx->ward_dist >= 2 || (ctx->ward_dist == 0 && n >= 4096));
     if (lw) {
         if (own_lo != 0 || own_hi != n) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "FAST mode builds the whole distance matrix on one GPU");
         ICL_TRY(icl_dist_mfma_launch(ctx, d_E, n, d, w->Dtri, w->rowoff, 0));
@@ -3490,8 +3871,19 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const double u = 5.9604644775390625e-08; // 2^-24
         const double gD = K * u / (1.0 - K * u), gp = std::pow(1.0 + u, d + 2) - 1.0;
         rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)),
-                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f};
+                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f};
+        {
+            // pairs with a merged member (the update kernel's bound body): chains of at most Dm products (the ring's whole stages) and the
+            // sums of the two k halves / two accumulators; the merged clusters' norms come from the same kind of chain:
+            //   | T - S/2 | <= (gDm + 16 u)(|a'|^2 + |b'|^2),  |a'|^2 <= n_a / (1 - gDm);   R in w S (1 -+ g_m), g_m = (1 + u)^(D + 8) - 1
+            const double Dm = (double)((wb_groups(d) + WX_SG - 1) / WX_SG * WX_SG) * 4 + 4;
+            const double gDm = Dm * u / (1.0 - Dm * u);
+            rf.ceps_m = (float)((gDm + 16 * u) * (1 + 2 * gDm + 64 * u) * (1 + 1e-6));
+            rf.gam_m = (float)((std::pow(1.0 + u, d + 8) - 1.0) * (1 + 1e-6));
+        }
         ICL_TRY(icl_dist_center_launch(ctx, d_E, n, d, K, w->colsum, (float *)g_ec.p, w->nrm, ctx->stream));
+        ICL_HIP(ctx, hipMemsetAsync(w->mu, 0, (size_t)w->cn_stride * sizeof(float), ctx->stream));
+        hipLaunchKernelGGL(ward_mu_kernel, dim3((unsigned)icl_ceil_div(d, 256)), dim3(256), 0, ctx->stream, w->colsum, n, d, w->mu);
         ICL_TRY(icl_dist_bound_launch(ctx, (const float *)g_ec.p, w->nrm, w->zero, n, K, rf.ceps, rf.gam, w->Dtri, w->rowoff, own_lo / DT_TILE,
                                       icl_ceil_div(own_hi, DT_TILE), ctx->stream));
     } else
@@ -3573,9 +3965,25 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // main workgroups: persistent, at most one per CU (they draw blocks from a counter); fewer when the input has fewer blocks
         const unsigned wx_blocks = (unsigned)std::min<int64_t>(w->S / 64, (int64_t)ctx->prop.multiProcessorCount) + 2 + WB_R;
         if (!w->wx_attr) { // per context, i.e. per device: a group drives one context per GPU
-            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             w->wx_attr = true;
         }
+        // Bound body of the update kernel (rows of the new clusters as lower bounds from the matrix cores): whenever the matrix holds
+        // bounds anyway, the shape fits (whole k-groups; ring + centring vector + static arrays inside the CU's 160 KB) and
+        // icl_set_ward_options has not asked for exact rows (ICL_DIST_BOUND_INIT)
+        const size_t wxb_lds_bytes = wx_lds_bytes + (size_t)((dqb + WX_SG - 1) / WX_SG * WX_SG) * 16;
+        bool upd_bound = !lw && rf.E && (d & 3) == 0 && ctx->ward_dist != 3;
+        if (upd_bound) {
+            hipFuncAttributes fa;
+            ICL_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)ward_update_batch2_kernel<true>));
+            if (wxb_lds_bytes + fa.sharedSizeBytes > 160 * 1024) upd_bound = false;
+            else if (w->wxb_attr < wxb_lds_bytes) {
+                ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wxb_lds_bytes));
+                w->wxb_attr = wxb_lds_bytes;
+            }
+        }
+        rf.upd = upd_bound ? 1 : 0;
+        const wx_bound_args wba{w->mu, w->nrm};
         // the express step's data phase runs in ward_finish_data_kernel from a record the finish kernel leaves behind cnewI
         int32_t *fdrec = (!lw && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
@@ -3595,9 +4003,17 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                                    w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
                 return;
             }
-            hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+            if (upd_bound) {
+                hipLaunchKernelGGL(ward_update_batch2_kernel<true>, dim3(wx_blocks), dim3(WX_THREADS), wxb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st,
+                                   max_size, n, w->rowmin, w->rownn, rf, wba);
+                hipLaunchKernelGGL(ward_newrow_min_kernel, dim3(WB_K), dim3(1024), 0, ctx->stream, n, w->cnew, w->cn_stride, w->rowoff, w->msz, w->mcid, w->Dtri,
+                                   w->st, max_size, rf);
+                return;
+            }
+            hipLaunchKernelGGL(ward_update_batch2_kernel<false>, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
-                               w->rowmin, w->rownn, rf);
+                               w->rowmin, w->rownn, rf, wba);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -3611,7 +4027,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         };
         finish_b(); // first batch: one pick by the plain lazy selection
         const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : upd_bound ? 4 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -3622,7 +4038,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = lw ? 3 : 2;
+            w->graph_lw = lw ? 3 : upd_bound ? 4 : 2;
             w->graph_E = rf.E;
             w->graph_ceps = rf.ceps;
         }
@@ -3883,7 +4299,7 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
 
 extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
 {
-    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_BOUND) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
+    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_BOUND_INIT) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->ward_dist = dist_mode;
     return ICL_OK;

@@ -277,14 +277,15 @@ def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
     E1 = (cen[rng.integers(0, 300, 6000)] * (1 + 1e-6 * rng.standard_normal((6000, 1)))).astype(np.float32)
     for E, mn, mx in [(E1, 5, 50), (WC.ties(5000, 5, 9, levels=6), 2, 30)]:
         res = []
-        for mode in (1, 2):
+        for mode in (1, 2, 3):  # exact everywhere / bounds in the initial matrix and the new rows / in the initial matrix only
             ctx.set_ward_options(mode)
             cid, rank, nc = ctx.cluster(E, mn, mx)
             res.append((cid.copy(), rank.copy(), nc, ctx.last_merges().copy(), ctx.last_merge_values().copy()))
         ctx.set_ward_options(0)
-        a, b = res
-        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
+        a = res[0]
+        for b in res[1:]:
+            assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
 
 
 def test_large_n_creation_ids_past_40960(ctx):
