@@ -76,8 +76,13 @@ struct ward_batch_state {
     unsigned long long sum_dep;                   // sum over steps of rows whose cached partner is a member of the batch
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
-    unsigned long long dbg[8], dbg_t0, dbg2[3];
-    unsigned long long rf_stat[8];   // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
+    // bound body of the update kernel: per new row, the smallest UPPER bound seen so far among the clusters that survive the batch
+    // (float bits; only ever lowered) and the number of columns appended to the row's candidate list (entries whose lower bound did
+    // not exceed that threshold when they were written + every valid entry of a later pick's member)
+    unsigned int ub2[WB_K];
+    int32_t cand_n[WB_K];
+    unsigned long long dbg[8], dbg_t0, dbg2[3], dbg3[4], dbg4[4], dbg5[4], dbg6[8];
+    unsigned long long rf_stat[12];  // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
     int32_t blk_next, blk_pad;       // the persistent main workgroups' block counter (zeroed every step by ward_interleave_kernel)
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
     int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
@@ -124,6 +129,9 @@ struct icl_ward_ws {
     float *nrm = nullptr;      // [capN] |E[r] - mu|^2 of the singletons: the scans' upper bounds of flagged entries (distance bounds)
     double *colsum = nullptr;  // [capD] column sums of E
     float *mu = nullptr;       // [cn_stride] the centring vector (zero padded): bound body of the update kernel
+    int32_t *cand = nullptr;   // [WB_K][WB_CAND_CAP] candidate columns of the rows being created (bound body)
+    int32_t *rl_cnt = nullptr, *rl_col = nullptr; // [M], [M][WB_RL] nearest-neighbour lists of the merged clusters' rows (bound body)
+    float *rl_B = nullptr;     // [M] their cover bounds
     size_t wxb_attr = 0;       // dynamic LDS the bound instantiation of the update kernel has been opted in for
     void *zero = nullptr;      // 256 zero bytes (LDS-DMA source of rows beyond n)
     int64_t dtri_floats = 0;
@@ -153,7 +161,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mu};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mu, w->cand, w->rl_cnt, w->rl_col, w->rl_B};
     for (auto &sp : w->staged)
         if (sp.second) (void)hipFree(sp.second);
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
@@ -491,7 +499,15 @@ struct wrefine {
     const float *Crow;       // [S][d] centroids by slot
     const int32_t *id_slot;  // creation id -> slot
     float ceps_m, gam_m;     // the constants of pairs with a merged member (distance_mfma.hip, "merged clusters")
+    // The nearest-neighbour list of a merged cluster's row (ward_newrow_min_kernel): the columns of its <= WB_RL smallest entries --
+    // all VALUES -- and a cover bound rl_B: every other entry that was valid when the row was created has a lower bound >= rl_B.
+    // A later scan of the row that finds a valid listed entry strictly below rl_B has the row's first minimum without reading
+    // the row (scan_row_min); rl_cnt == 0: no list.
+    int32_t *rl_cnt;
+    float *rl_B;
+    int32_t *rl_col;         // [creation id][WB_RL]
 };
+#define WB_RL 16
 __device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
 // w2 = 2 fl(sa sb / (sa + sb)) (1 for two singletons); merged: the row belongs to a merged cluster
 __device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf, float w2 = 1.0f, bool merged = false)
@@ -570,6 +586,66 @@ __device__ __forceinline__ float ward_pair_value(const float *__restrict__ x, co
     const float den = (float)(sx + sy);                    // :143
     return (num / den) * s;                                // :144
 }
+// The same sum by a whole wave (d % 4 == 0; call with all 64 lanes active; the result is wave-uniform): the lanes load 64 k-groups
+// at a time (two coalesced 1 KB loads), form the rounded squares fl(fl(x_k - y_k)^2) side by side and park them in the wave's
+// 1 KB of LDS; the running sum then takes them strictly in k order from broadcast 16-byte reads -- the only serial part is the
+// chain of d additions the reference's rounding demands (~6 us at D = 2048; one thread walking both rows alone takes ~100 us:
+// its loads depend on nothing but each waits for the previous iteration's).  scratch: 256 floats of this wave's own.
+__device__ __forceinline__ float ward_sqdist_wave(const float *__restrict__ x, const float *__restrict__ y, int d, float *scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int ng = d >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    float4 *sc4 = reinterpret_cast<float4 *>(scratch);
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xv = lane < ng ? x4[lane] : z4, yv = lane < ng ? y4[lane] : z4;
+    float s = 0.0f;
+    for (int g0 = 0; g0 < ng; g0 += 64) {
+        const int gn = g0 + 64 + lane;
+        const float4 nx = gn < ng ? x4[gn] : z4, ny = gn < ng ? y4[gn] : z4; // the next 64 groups: in flight during the serial part
+        const float d0 = xv.x - yv.x, d1 = xv.y - yv.y, d2 = xv.z - yv.z, d3 = xv.w - yv.w; // clustering.go:139
+        sc4[lane] = make_float4(d0 * d0, d1 * d1, d2 * d2, d3 * d3);                           // :154 products
+        __builtin_amdgcn_wave_barrier();
+        const int nl = ng - g0 < 64 ? ng - g0 : 64;
+        int l = 0;
+        if (nl >= 4) { // :154 sums, strictly in k order; the next four reads are in flight while the current sixteen terms are added
+            float4 p0 = sc4[0], p1 = sc4[1], p2 = sc4[2], p3 = sc4[3];
+            for (l = 4; l + 4 <= nl; l += 4) {
+                const float4 q0 = sc4[l], q1 = sc4[l + 1], q2 = sc4[l + 2], q3 = sc4[l + 3];
+                __builtin_amdgcn_sched_barrier(0); // (hipcc otherwise sinks the reads below the additions and waits for them at once)
+                s = s + p0.x; s = s + p0.y; s = s + p0.z; s = s + p0.w;
+                s = s + p1.x; s = s + p1.y; s = s + p1.z; s = s + p1.w;
+                s = s + p2.x; s = s + p2.y; s = s + p2.z; s = s + p2.w;
+                s = s + p3.x; s = s + p3.y; s = s + p3.z; s = s + p3.w;
+                p0 = q0;
+                p1 = q1;
+                p2 = q2;
+                p3 = q3;
+            }
+            s = s + p0.x; s = s + p0.y; s = s + p0.z; s = s + p0.w;
+            s = s + p1.x; s = s + p1.y; s = s + p1.z; s = s + p1.w;
+            s = s + p2.x; s = s + p2.y; s = s + p2.z; s = s + p2.w;
+            s = s + p3.x; s = s + p3.y; s = s + p3.z; s = s + p3.w;
+        }
+        for (; l < nl; ++l) {
+            const float4 p0 = sc4[l];
+            s = s + p0.x; s = s + p0.y; s = s + p0.z; s = s + p0.w;
+        }
+        __builtin_amdgcn_wave_barrier(); // the reads are done before the next chunk overwrites the scratch
+        xv = nx;
+        yv = ny;
+    }
+    return s;
+}
+// where the centroid of cluster `id` stands during the merge loop (singletons of a singleton row: straight from E)
+__device__ __forceinline__ const float *wcentroid(const wrefine &rf, int id) { return rf.Crow + (int64_t)rf.id_slot[id] * rf.d; }
+__device__ __forceinline__ float ward_scale(float s, int sx, int sy)
+{
+    const float num = (float)((int64_t)sx * (int64_t)sy); // :142
+    const float den = (float)(sx + sy);                    // :143
+    return (num / den) * s;                                // :144
+}
+
 // the value behind a flagged entry of row my_id (size my_size; its centroid: my_cent, or looked up) against cluster c (size m)
 __device__ __forceinline__ float wpair_value(const wrefine &rf, int my_id, int my_size, const float *my_cent, int c, int m)
 {
@@ -650,8 +726,9 @@ __device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float 
 
 __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine rf, float tv0, int ti0, float thr0, const float *my_cent)
+                                             const wrefine rf, float tv0, int ti0, float thr0, const float *my_cent, float *scr)
 {
+    // scr: 256 floats of LDS per wave of the workgroup (ward_sqdist_wave's scratch), 16-byte aligned
     // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
     __shared__ int ref_cnt;
     __shared__ int ref_col[WB_REF_CAP];
@@ -712,6 +789,20 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         }
         float rv = ICL_MAXF;
         int ri = -1;
+        if ((rf.d & 3) == 0 && m <= 3 * (int)(blockDim.x >> 6)) { // a few entries: one per WAVE at a time (ward_sqdist_wave); many: one per thread
+            const float *yc = mrow ? (my_cent ? my_cent : wcentroid(rf, my_id)) : rf.E + (int64_t)my_id * rf.d;
+            for (int q = threadIdx.x >> 6; q < m; q += (int)(blockDim.x >> 6)) {
+                const int col = ref_col[q];
+                const int c = mcid[col];
+                const float *xc = mrow ? wcentroid(rf, c) : rf.E + (int64_t)c * rf.d;
+                const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr + (threadIdx.x >> 6) * 256), mrow ? msz[col] : 1, mrow ? my_size : 1);
+                if ((threadIdx.x & 63) == 0) row[col] = val; // a value from now on
+                if (val < rv || (val == rv && c < ri)) {
+                    rv = val;
+                    ri = c;
+                }
+            }
+        } else
         for (int q = threadIdx.x; q < m; q += blockDim.x) {
             const int col = ref_col[q];
             const int c = mcid[col];
@@ -767,6 +858,50 @@ __device__ __forceinline__ void block_argmin2(float &v0, int &i0, float &v1, int
     __syncthreads(); // the scratch may be rewritten
 }
 
+// block_argmin2 with the second smallest of the plain minimum's stream: (v0, i0) lexicographic; (v1, i1) smallest v1, any index;
+// w1 = second smallest of all v1 values seen
+__device__ __forceinline__ void block_argmin2b(float &v0, int &i0, float &v1, int &i1, float &w1, float *sv, int *si)
+{
+    auto join = [](float &a, int &ai, float &aw, float b, int bi, float bw) {
+        const float hi = a < b ? b : a; // the larger of the two minima is a candidate for the second smallest
+        if (b < a) {
+            a = b;
+            ai = bi;
+        }
+        aw = fminf(fminf(aw, bw), hi);
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_down(v0, off, 64), b = __shfl_down(v1, off, 64), bw = __shfl_down(w1, off, 64);
+        const int ai = __shfl_down(i0, off, 64), bi = __shfl_down(i1, off, 64);
+        argmin_combine(v0, i0, a, ai);
+        join(v1, i1, w1, b, bi, bw);
+    }
+    __shared__ float v2[16], w2[16];
+    __shared__ int i2[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sv[wid] = v0;
+        si[wid] = i0;
+        v2[wid] = v1;
+        i2[wid] = i1;
+        w2[wid] = w1;
+    }
+    __syncthreads();
+    float a = sv[0], b = v2[0], bw = w2[0];
+    int ai = si[0], bi = i2[0];
+    for (int w = 1; w < nw; ++w) { // every thread reduces the <= 16 wave results itself
+        argmin_combine(a, ai, sv[w], si[w]);
+        join(b, bi, bw, v2[w], i2[w], w2[w]);
+    }
+    v0 = a;
+    i0 = ai;
+    v1 = b;
+    i1 = bi;
+    w1 = bw;
+    __syncthreads(); // the scratch may be rewritten
+}
+
 // The row scan of every merge-loop kernel: result reduced over the workgroup.
 // Rows that may hold bounds (singleton rows while rf.E is set): ONE pass finds the first minimum among VALUES and the smallest
 // lower bound among flagged entries.  If the best value is strictly below every bound, every flagged entry's true value is
@@ -776,7 +911,7 @@ __device__ __forceinline__ void block_argmin2(float &v0, int &i0, float &v1, int
 // more than WB_REF_CAP of them: its full loop).
 __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine &rf, const float *my_cent = nullptr)
+                                             const wrefine &rf, float *scr, const float *my_cent = nullptr)
 {
     if (!(rf.E && (my_id < rf.n || rf.upd))) {
         scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi);
@@ -788,16 +923,57 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
         return hit;
     };
-    float tv = ICL_MAXF, lv = ICL_MAXF;
+    if (my_id >= rf.n && rf.rl_cnt && !my_cent) {
+        // a merged cluster's row: its nearest-neighbour list first (wave 0; columns are recycled, so every entry is re-validated:
+        // a column now owned by a younger cluster fails c < my_id, a dead one msz > 0)
+        const int k = rf.rl_cnt[my_id];
+        if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[k > 0 ? 8 : 10], 1ull);
+        if (k > 0) {
+            if (threadIdx.x < 64) {
+                float v = ICL_MAXF;
+                int c = -1;
+                if ((int)threadIdx.x < k) {
+                    const int col = rf.rl_col[(int64_t)my_id * WB_RL + threadIdx.x];
+                    const int m = msz[col], cc = mcid[col];
+                    const float e = row[col];
+                    if (m > 0 && m + my_size <= max_size && cc < my_id && !wflagged(e) && !excluded(cc)) {
+                        v = e;
+                        c = cc;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) argmin_combine(v, c, __shfl_down(v, off, 64), __shfl_down(c, off, 64));
+                if (threadIdx.x == 0) {
+                    sv[0] = v;
+                    si[0] = c;
+                }
+            }
+            __syncthreads();
+            const float lv_ = sv[0];
+            const int lc_ = si[0];
+            __syncthreads();
+            if (lc_ >= 0 && lv_ < rf.rl_B[my_id]) { // strictly below everything outside the list
+                bv = lv_;
+                bi = lc_;
+                if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[9], 1ull);
+                return;
+            }
+        }
+    }
+    float tv = ICL_MAXF, lv = ICL_MAXF, lv2 = ICL_MAXF; // lv2: the second smallest lower bound (an excluded entry may count: it only errs low)
     int ti = -1, lc = -1;
     ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
         if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
         if (wflagged(v)) {
             const float L = fabsf(v);
-            if (L < lv && !excluded(c)) { // (lc: the COLUMN of an entry with the smallest lower bound, any of them)
-                lv = L;
-                lc = col;
-            }
+            if (L < lv) { // (lc: the COLUMN of an entry with the smallest lower bound, any of them)
+                if (!excluded(c)) {
+                    lv2 = lv;
+                    lv = L;
+                    lc = col;
+                }
+            } else if (L < lv2)
+                lv2 = L;
         } else if (v < tv || (v == tv && c < ti)) {
             if (!excluded(c)) {
                 tv = v;
@@ -805,7 +981,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
             }
         }
     });
-    block_argmin2(tv, ti, lv, lc, sv, si);
+    block_argmin2b(tv, ti, lv, lc, lv2, sv, si);
     if (lc < 0 || lv > tv) { // no bound at or below the best value
         bv = tv;
         bi = ti;
@@ -813,9 +989,43 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
     }
     if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
     const bool mrow = my_id >= rf.n;
+    if ((rf.d & 3) == 0 && rf.margin == 0.0f) {
+        // The entry with the smallest bound is evaluated straight away (one wave).  If the best value then lies strictly below the
+        // SECOND smallest bound, every other flagged entry is strictly above it: done after one pass and one evaluation (the bounds
+        // sit ~1e-4 below the values, the smallest entries of a row lie ~1e-3 apart).  Otherwise the value is the threshold of the
+        // collecting pass below.
+        const int c = mcid[lc];
+        if (threadIdx.x < 64) {
+            const float *yc = mrow ? (my_cent ? my_cent : wcentroid(rf, my_id)) : rf.E + (int64_t)my_id * rf.d;
+            const float *xc = mrow ? wcentroid(rf, c) : rf.E + (int64_t)c * rf.d;
+            const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr), mrow ? msz[lc] : 1, mrow ? my_size : 1);
+            if (threadIdx.x == 0) {
+                row[lc] = val; // a value from now on
+                sv[0] = val;
+                if (rf.stat) {
+                    atomicAdd(&rf.stat[2], 1ull);
+                    atomicAdd(&rf.stat[3], 1ull);
+                }
+            }
+        }
+        __syncthreads();
+        const float val = sv[0];
+        __syncthreads();
+        if (val < tv || (val == tv && c < ti)) {
+            tv = val;
+            ti = c;
+        }
+        if (tv < lv2) {
+            bv = tv;
+            bi = ti;
+            return;
+        }
+        scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, my_cent, scr);
+        return;
+    }
     const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf, mrow ? ward_w2(msz[lc], my_size) : 1.0f, mrow);
     const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
-    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, my_cent);
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, my_cent, scr);
 }
 
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
@@ -826,6 +1036,7 @@ __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(float *__restrict_
 {
     __shared__ float sv[16];
     __shared__ int si[16];
+    __shared__ __attribute__((aligned(16))) float scr[16][256];
     for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
         const int my = asz[r];
         float bv;
@@ -835,7 +1046,7 @@ __global__ __launch_bounds__(1024) void row_argmin_tri_kernel(float *__restrict_
             bi = -1;
         } else {
             const int noex[1] = {-1};
-            scan_row_min(Dtri + rowoff[r], r, msz, mcid, (int)r, my, max_size, noex, 0, bv, bi, sv, si, rf);
+            scan_row_min(Dtri + rowoff[r], r, msz, mcid, (int)r, my, max_size, noex, 0, bv, bi, sv, si, rf, &scr[0][0]);
         }
         if (threadIdx.x == 0) {
             rowmin[r] = bv;
@@ -928,10 +1139,18 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
         st->B.ov_n = 0;
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
+        for (int j = 0; j < WB_K; ++j) {
+            st->B.ub2[j] = 0x7f7fffffu;
+            st->B.cand_n[j] = 0;
+        }
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         st->B.blk_next = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
-        for (int j = 0; j < 8; ++j) st->B.rf_stat[j] = 0;
+        for (int j = 0; j < 4; ++j) st->B.dbg3[j] = st->B.dbg4[j] = 0;
+        st->B.dbg4[3] = ~0ull;
+        for (int j = 0; j < 4; ++j) st->B.dbg5[j] = 0;
+        for (int j = 0; j < 8; ++j) st->B.dbg6[j] = 0;
+        for (int j = 0; j < 12; ++j) st->B.rf_stat[j] = 0;
     }
 }
 
@@ -990,6 +1209,7 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
                                                const int32_t *__restrict__ mcid, int max_size, ward_state *__restrict__ st,
                                                float *sv, int *si, int *sh, const wrefine &rf)
 {
+    __shared__ __attribute__((aligned(16))) float pre_scr[16][256]; // ward_sqdist_wave's scratch
     if (st->done) return;
     const int t = st->t;
     if (t >= st->target) return;
@@ -1034,7 +1254,7 @@ __device__ __forceinline__ void ward_preselect(int64_t n, const int32_t *__restr
         int ri;
         {
             const int noex[1] = {-1};
-            scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf);
+            scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf, &pre_scr[0][0]);
         }
         if (threadIdx.x == 0) {
             rowmin[bi] = rv;
@@ -1586,12 +1806,21 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         }
     }
     __syncthreads();
+    WB_TIMER(const unsigned long long tb0 = wall_clock64();)
+    WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg6[0], tb0);) // latest end of phase A over the spare workgroups (absolute)
     for (int m = 0; m < WB_RM; ++m) {
         const int r = mine[m];
         float rv = ICL_MAXF;
         int ri = -1;
         if (r >= 0) {
-            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf);
+            WB_TIMER(const unsigned long long tr0 = wall_clock64();)
+            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf, sv + 1024);
+            WB_TIMER(if (threadIdx.x == 0) {
+                const unsigned long long dt = wall_clock64() - tr0;
+                atomicAdd(&st->B.dbg6[r < n ? 2 : 4], dt);   /* time in rescans: singleton rows / merged rows */
+                atomicAdd(&st->B.dbg6[r < n ? 3 : 5], 1ull); /* their number */
+                atomicMax(&st->B.dbg6[6], dt);
+            })
         }
         if (threadIdx.x == 0) {
             st->B.spec_row[m * WB_R + wg] = r;
@@ -1801,7 +2030,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf); // ends with a barrier: cmd may be rewritten afterwards
+        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf, sv + 1024); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
                 if (ri < 0) {
@@ -2054,9 +2283,14 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
 // dirty-column handling are those of the exact body below; the centroid area of a stage holds [k-group][new cluster] float4.
 // |c'|^2 of the new clusters: the diagonal of their Gram matrix, by the same instruction on the same registers (column block 0's
 // two waves, in the workgroup's first block); every workgroup computes the same bits and stores them to nrm[] for later steps.
+#define WB_CAND_CAP 4096 /* columns a new row's candidate list holds (more: ward_newrow_min_kernel scans the row) */
+#define WB_LCAP 48       /* ... a workgroup collects per row before it appends to the global list directly */
+#define WB_NR_CAP 512    /* candidates ward_newrow_min_kernel ranks (more: it scans the row) */
+#define WB_LMARGIN 0.04f /* candidates are collected up to (1 + margin) x the threshold: ~16 nearest neighbours per row at N = 100 000 ResNet embeddings */
 struct wx_bound_args {
     const float *mu;  // [>= 4 (dqp + WX_SG)] the centring vector of the distance bounds, zero padded
     float *nrm;       // [n + merges] |centroid - mu|^2 by creation id
+    int32_t *cand;    // [WB_K][WB_CAND_CAP] candidate columns of the rows being created
 };
 
 __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, int64_t S, float *__restrict__ CT, const float *__restrict__ Crow,
@@ -2075,6 +2309,12 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
     __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_mx[2][64], nx_dirty[2][64];
     __shared__ float4 part[4][64];   // the accumulators of the upper k half, by column block
     __shared__ float nrc_p[2][WB_K]; // |c'_j|^2 of the new clusters: the two k halves
+    __shared__ float ubc_l[WB_K];    // the rows' candidate thresholds as last seen (st->B.ub2: only ever lowered, so a stale value is a superset)
+    // candidates collected by this workgroup, flushed to the rows' global lists once, when its last block is done (a device
+    // atomic with a return value per candidate cost the epilogue 12 of its 15 us per block)
+    __shared__ int lc_cnt[WB_K], lc_col[WB_K][WB_LCAP];
+    __shared__ float lc_L[WB_K][WB_LCAP];
+    if (threadIdx.x < WB_K) lc_cnt[threadIdx.x] = 0;
     if (threadIdx.x < WB_K) {
         pa[threadIdx.x] = st->B.a[threadIdx.x];
         pb[threadIdx.x] = st->B.b[threadIdx.x];
@@ -2085,11 +2325,11 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
     float4 *mu_l = wb_lds + WX_R * WX_STAGE_F4; // the centring vector, by k-group
     for (int g = threadIdx.x; g < nstage * WX_SG; g += WX_THREADS) mu_l[g] = reinterpret_cast<const float4 *>(ba.mu)[g];
     __syncthreads();
-    const int nmain = (int)gridDim.x - (WB_R + 2);
     int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_mx = 0, pf_dirty = 0; // chain wave 0 only
     auto pf_advance = [&](const int upto, const int par) { // (the exact body's prefetch of the next block's state: see there)
-        if (pf_done < 1 && upto >= 1) {
-            pf_raw = lane == 0 ? nmain + atomicAdd(&st->B.blk_next, 1) : 0;
+        if (pf_done < 1 && upto >= 1) { // every block comes from the counter, the first one too: a workgroup that starts late (its CU ran a
+            // spare / preselection workgroup first) must not sit on a reserved block while the others run out of work
+            pf_raw = lane == 0 ? atomicAdd(&st->B.blk_next, 1) : 0;
             pf_done = 1;
         }
         if (pf_done < 2 && upto >= 2) {
@@ -2119,11 +2359,8 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
             pf_done = 4;
         }
     };
-    if (wave == 0) {
-        pf_raw = (int)blockIdx.x - (WB_R + 2);
-        pf_done = 1;
-        pf_advance(4, 0);
-    }
+    if (wave == 0) pf_advance(4, 0);
+    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
     int rp = 0;
     bool pre = false;
     bool gram_done = false; // the new clusters' norms are in nrc_p (computed in this workgroup's first computed block)
@@ -2139,7 +2376,30 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
         const int64_t mblk = __builtin_amdgcn_readfirstlane(nx_blk[par]);
         rp = __builtin_amdgcn_readfirstlane(rp);
         pf_done = 0;
-        if (mblk < 0 || mblk * 64 >= nlive) break;
+        if (mblk < 0 || mblk * 64 >= nlive) {
+            // flush this workgroup's candidates (every epilogue has passed the barrier above): one thread per row keeps what the
+            // threshold as it stands now still admits -- any value read here is >= the final one -- and appends with ONE atomic
+            if (threadIdx.x < WB_K && lc_cnt[threadIdx.x] > 0) {
+                const int j = threadIdx.x, cnt = lc_cnt[j] < WB_LCAP ? lc_cnt[j] : WB_LCAP;
+                const float thr = __uint_as_float(__hip_atomic_load(&st->B.ub2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                int k = 0;
+                const float thr_m = thr < 1e37f ? thr * (1.0f + WB_LMARGIN) : thr;
+                for (int i = 0; i < cnt; ++i) k += lc_L[j][i] <= thr_m ? 1 : 0;
+                if (k > 0) {
+                    int at = atomicAdd(&st->B.cand_n[j], k);
+                    for (int i = 0; i < cnt; ++i)
+                        if (lc_L[j][i] <= thr_m) {
+                            if (at < WB_CAND_CAP) ba.cand[j * WB_CAND_CAP + at] = lc_col[j][i];
+                            ++at;
+                        }
+                }
+            }
+            WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg3[3], wall_clock64());)
+            WB_TIMER(if (threadIdx.x == 0) atomicMin(&st->B.dbg4[3], tm0);)
+            WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[1] += wall_clock64() - tm0;)
+            WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) st->B.dbg[2] += wall_clock64() - tm0;)
+            break;
+        }
         const int64_t slot = mblk * 64 + lane;
         const bool dirty_lane = nx_dirty[par][lane] != 0;
         const bool any_dirty = __any(dirty_lane);
@@ -2171,6 +2431,7 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
         // which rows does this lane's cluster (lane = slot of the block) take part in?  Every wave computes the same masks.
         const int x = nx_x[par][lane], sx = nx_sx[par][lane];
         unsigned okmask = 0;
+        bool survives;
         {
             bool alive = x >= 0 && sx > 0;
 #pragma unroll
@@ -2180,7 +2441,10 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
                     if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
                 }
             }
+            survives = alive; // not a member of any pick of the batch
         }
+        if (wave == WX_CW - 1 && lane < WB_K) // (a chain wave without an epilogue; the stage barriers order this against the epilogue's reads)
+            ubc_l[lane] = __uint_as_float(__hip_atomic_load(&st->B.ub2[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (!__any(okmask != 0)) {
             if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (wave == 0) pf_advance(4, par ^ 1);
@@ -2227,6 +2491,7 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
         };
         int nxt_blk = -1;
         bool nxt_on = false, nxt_dirty = false;
+        WB_TIMER(const unsigned long long ts0 = wall_clock64();)
         for (int i = 0; i < nstage; ++i) {
             if (loader) {
                 if (i + WX_R - 2 < nstage || nxt_on)
@@ -2263,6 +2528,8 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
         if (wave == 0) pf_advance(4, par ^ 1);
         rp = (rp + nstage) % WX_R;
         pre = nxt_on;
+        WB_TIMER(const unsigned long long ts1 = wall_clock64();)
+        WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) { st->B.dbg3[0] += ts1 - ts0; st->B.dbg3[2] += 1; })
         // ---- the two k halves meet: the upper half's sums (and the norms' halves) go through LDS
         f32x4 acc = acc0 + acc1;
         if (!loader && hk == 1) part[cb][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -2282,25 +2549,63 @@ __device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, in
             acc[2] += o.z;
             acc[3] += o.w;
         }
+        // nrm_x has been in flight since the block began: ONE wait here.  Left to the compiler, every use inside the conditional code
+        // below waits with vmcnt(0) again -- by then for the scattered stores of the previous row (4 x 2.5 us per block).
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0" : "+v"(nrm_x)::"memory");
         const unsigned okm = (unsigned)__shfl((int)okmask, cb * 16 + lc, 64);
+        const bool surv_e = __shfl((int)survives, cb * 16 + lc, 64) != 0;
         const int sxe = nx_sx[par][cb * 16 + lc];
-        const int64_t mxe = nx_mx[par][cb * 16 + lc];
+        const int mxe = nx_mx[par][cb * 16 + lc];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int j = 4 * lq + v; // the new cluster c_j
-            if (j < nb && ((okm >> j) & 1u)) {
+            const bool valid = j < nb && ((okm >> j) & 1u);
+            float L = 0.0f, U = ICL_MAXF;
+            if (valid) {
                 const int sc = psc[j];
                 const float ns = nrm_x + (nrc_p[0][j] + nrc_p[1][j]);
                 const float T = 0.5f * ns - acc[v];
                 const float num = (float)((int64_t)sxe * (int64_t)sc), den = (float)(sxe + sc);
+                const float w2 = 2.0f * (num / den);
                 // 2 w (T - E)(1 - g'), pushed down against the roundings of this expression itself (distance_mfma.hip, "merged clusters")
-                float L = (T - rf.ceps_m * ns) * (1.0f - rf.gam_m);
-                L = (2.0f * (num / den)) * L;
+                L = (T - rf.ceps_m * ns) * (1.0f - rf.gam_m);
+                L = w2 * L;
                 L = L * (1.0f - 6e-7f);
                 L = (L > 1e-30f && ns < 1e37f) ? L : 0.0f; // subnormal range / overflowing norms (also NaN): no claim
                 Dtri[ro_l[j] + mxe] = __uint_as_float(__float_as_uint(L) | 0x80000000u);
+                if (surv_e) {
+                    U = wupper(L, ns, rf, w2, true);
+                    U = U < ICL_MAXF ? U : ICL_MAXF; // (NaN / +inf: no claim)
+                }
+            }
+            // candidates of the row's minimum: the threshold is the smallest upper bound seen so far among the survivors (the row's
+            // minimum over them cannot exceed it); whatever is at or below it when written -- and every entry of a later pick's
+            // member -- goes on the row's list, a superset of the final band (ward_newrow_min_kernel filters with the final value)
+            float Um = U; // minimum over the 16 lanes of this lane's row group (DPP: quad swaps, then the row's mirrors)
+            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0xB1, 0xf, 0xf, false)));  // quad_perm:[1,0,3,2]
+            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x4E, 0xf, 0xf, false)));  // quad_perm:[2,3,0,1]
+            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x141, 0xf, 0xf, false))); // row_half_mirror
+            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x140, 0xf, 0xf, false))); // row_mirror
+            float thr = ubc_l[j & (WB_K - 1)];
+            if (Um < thr) {
+                if (lc == 0) {
+                    atomicMin(&st->B.ub2[j], __float_as_uint(Um));
+                    ubc_l[j] = Um;
+                }
+                thr = Um;
+            }
+            if (valid && (!surv_e || L <= thr * (1.0f + WB_LMARGIN))) { // (the margin: the row's nearest-neighbour list, ward_newrow_min_kernel)
+                const int at = atomicAdd(&lc_cnt[j], 1);
+                if (at < WB_LCAP) {
+                    lc_col[j][at] = mxe;
+                    lc_L[j][at] = L;
+                } else {
+                    const int ag = atomicAdd(&st->B.cand_n[j], 1);
+                    if (ag < WB_CAND_CAP) ba.cand[j * WB_CAND_CAP + ag] = mxe;
+                }
             }
         }
+        WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg3[1] += wall_clock64() - ts1;)
     } // block loop
 }
 
@@ -2327,6 +2632,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
         ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf);
+        WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg5[0], wall_clock64());)
         return;
     }
     if (blockIdx.x == WB_R) {
@@ -2623,34 +2929,144 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
 __global__ __launch_bounds__(1024) void ward_newrow_min_kernel(int64_t n, const float *__restrict__ cnewK, int64_t cn_stride,
                                                               const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                                               const int32_t *__restrict__ mcid, float *__restrict__ Dtri, ward_state *__restrict__ st,
-                                                              int max_size, const wrefine rf)
+                                                              int max_size, const wrefine rf, const int32_t *__restrict__ cand,
+                                                              const int32_t *__restrict__ mcol)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int ex[2 * WB_K];
+    __shared__ int nref;
+    __shared__ int rcol[WB_NR_CAP], rcid[WB_NR_CAP], rmsz[WB_NR_CAP], rslot[WB_NR_CAP];
+    __shared__ float rval[WB_NR_CAP];
+    __shared__ int evq[WB_NR_CAP], rlat[WB_NR_CAP], rl_tmp[WB_RL], nev, nlist;
+    __shared__ unsigned covB;
+    __shared__ __attribute__((aligned(16))) float scr[16][256];
     const int j = blockIdx.x;
     if (st->done) return;
     const int nb = st->B.nb, t = st->t;
     if (j >= nb) return;
+    WB_TIMER(const unsigned long long tn0 = wall_clock64();)
     if (threadIdx.x < 2 * WB_K) {
         const int q = threadIdx.x >> 1;
         ex[threadIdx.x] = q < nb ? ((threadIdx.x & 1) ? st->B.b[q] : st->B.a[q]) : -1;
     }
+    if (threadIdx.x == 0) nref = 0;
     __syncthreads();
     const int my_id = (int)(n + t + j), my_size = st->B.sa[j] + st->B.sb[j];
     float *row = Dtri + rowoff[my_id];
     const float *cent = cnewK + (int64_t)j * cn_stride;
-    float v1, v2;
-    int i1, i2;
-    scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * (j + 1), v1, i1, sv, si, rf, cent);
-    bool later = false;
-    for (int z = 2 * (j + 1); z < 2 * nb; ++z) later |= i1 >= 0 && ex[z] == i1;
-    v2 = v1;
-    i2 = i1;
-    if (later) scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * nb, v2, i2, sv, si, rf, cent);
+    auto member = [&](int c, int z0) { // is c a member of a pick z0/2 or later?
+        bool hit = false;
+        for (int z = z0; z < 2 * nb; ++z) hit |= ex[z] == c;
+        return hit;
+    };
+    float v1 = ICL_MAXF, v2 = ICL_MAXF;
+    int i1 = -1, i2 = -1;
+    const int cn = st->B.cand_n[j];
+    bool listed = cn <= WB_CAND_CAP && (rf.d & 3) == 0;
+    const float thr = __uint_as_float(st->B.ub2[j]);
+    const float thr_m = thr < 1e37f ? thr * (1.0f + WB_LMARGIN) : thr;
+    if (listed) {
+        // The list the update kernel's workgroups left.  The FINAL threshold thr is the smallest upper bound among the survivors: the
+        // row's minimum over them -- and with it the minimum over all clusters alive at c_j's time -- cannot exceed it, so the
+        // entries with a bound <= thr (the band) decide both minima.  Candidates up to (1 + margin) thr are kept as well: the
+        // survivors among them are the row's nearest neighbours.
+        for (int q = threadIdx.x; q < cn; q += blockDim.x) {
+            const int col = cand[j * WB_CAND_CAP + q];
+            const float v = row[col];
+            if (fabsf(v) <= thr_m) {
+                const int at = atomicAdd(&nref, 1);
+                if (at < WB_NR_CAP) { // everything the evaluation needs, fetched here by as many threads as there are candidates
+                    const int c = mcid[col];
+                    rcol[at] = col;
+                    rcid[at] = c;
+                    rmsz[at] = msz[col];
+                    rslot[at] = rf.id_slot[c];
+                    rval[at] = v;
+                }
+            }
+        }
+        __syncthreads();
+        listed = nref <= WB_NR_CAP;
+    }
+    WB_TIMER(if (threadIdx.x == 0 && j == 0) st->B.dbg2[1] += wall_clock64() - tn0;)
+    if (listed) {
+        // rank the survivors by lower bound: the WB_RL smallest form the row's nearest-neighbour list, the smallest bound among the
+        // others (or the collection limit) is its cover bound.  Evaluated: the list, and whatever else lies in the band.
+        const int m = nref;
+        if (threadIdx.x == 0) {
+            nev = 0;
+            nlist = 0;
+            covB = __float_as_uint(thr_m);
+        }
+        for (int i = threadIdx.x; i < m; i += blockDim.x) rlat[i] = member(rcid[i], 0) ? 1 : 0; // (members of the picks up to j never enter the lists: okmask)
+        __syncthreads();
+        // the virtual-slot entries D(c_j, c_i), i < j, are values outside the list: they lower the cover bound
+        if ((int)threadIdx.x < j) {
+            const int i = threadIdx.x, sci = st->B.sa[i] + st->B.sb[i];
+            if (sci + my_size <= max_size) {
+                const float v = row[mcol[ex[2 * i]]];
+                if (v >= 0.0f) atomicMin(&covB, __float_as_uint(v)); // (NaN: never a minimum)
+            }
+        }
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const float Li = fabsf(rval[i]);
+            const bool later = rlat[i] != 0;
+            int rank = 0;
+            if (!later)
+                for (int q = 0; q < m; ++q) {
+                    const float Lq = fabsf(rval[q]);
+                    rank += (Lq < Li || (Lq == Li && q < i)) && !rlat[q] ? 1 : 0;
+                }
+            const bool in_list = !later && rank < WB_RL;
+            if (!later && !in_list) atomicMin(&covB, __float_as_uint(Li));
+            if (in_list) rl_tmp[atomicAdd(&nlist, 1)] = rcol[i];
+            if (in_list || Li <= thr) evq[atomicAdd(&nev, 1)] = i;
+        }
+        __syncthreads();
+        const int ne = nev;
+        if (rf.stat && threadIdx.x == 0) {
+            atomicAdd(&rf.stat[0], 1ull);
+            atomicAdd(&rf.stat[2], 1ull);
+            atomicAdd(&rf.stat[3], (unsigned long long)ne);
+        }
+        for (int e = threadIdx.x >> 6; e < ne; e += (int)(blockDim.x >> 6)) { // one entry per wave at a time
+            const int q = evq[e];
+            const int col = rcol[q];
+            const int c = rcid[q];
+            float val = rval[q];
+            if (wflagged(val)) {
+                val = ward_scale(ward_sqdist_wave(rf.Crow + (int64_t)rslot[q] * rf.d, cent, rf.d, scr[threadIdx.x >> 6]), rmsz[q], my_size);
+                if ((threadIdx.x & 63) == 0) row[col] = val; // a value from now on
+            }
+            if (val < v1 || (val == v1 && c < i1)) {
+                v1 = val;
+                i1 = c;
+            }
+            if (!member(c, 0) && (val < v2 || (val == v2 && c < i2))) {
+                v2 = val;
+                i2 = c;
+            }
+        }
+        block_argmin2(v1, i1, v2, i2, sv, si);
+        // the row's list for later scans (scan_row_min)
+        if (threadIdx.x < WB_RL && (int)threadIdx.x < nlist) rf.rl_col[(int64_t)my_id * WB_RL + threadIdx.x] = rl_tmp[threadIdx.x];
+        if (threadIdx.x == 0) {
+            rf.rl_cnt[my_id] = nlist;
+            rf.rl_B[my_id] = __uint_as_float(covB);
+        }
+    } else {
+        // too many candidates (heavy ties): scan the row.  The second scan only runs when the first minimum is a later pick's member.
+        scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * (j + 1), v1, i1, sv, si, rf, &scr[0][0], cent);
+        v2 = v1;
+        i2 = i1;
+        if (i1 >= 0 && member(i1, 2 * (j + 1))) scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * nb, v2, i2, sv, si, rf, &scr[0][0], cent);
+        if (threadIdx.x == 0) rf.rl_cnt[my_id] = 0;
+    }
     if (threadIdx.x == 0) {
         if (i1 >= 0 && v1 < ICL_MAXF) atomicMin(&st->B.ckey[j], ((unsigned long long)__float_as_uint(v1) << 32) | (unsigned)i1);
         if (i2 >= 0 && v2 < ICL_MAXF) atomicMin(&st->B.ckey2[j], ((unsigned long long)__float_as_uint(v2) << 32) | (unsigned)i2);
+        WB_TIMER(if (j == 0) st->B.dbg2[2] += wall_clock64() - tn0;)
     }
 }
 
@@ -2842,7 +3258,19 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
     __shared__ int cm_slot_a[WB_K], cm_from[WB_K], cm_to[WB_K];
     __shared__ int pk_a[WB_K], pk_b[WB_K], pk_sa[WB_K], pk_sb[WB_K], pk_sla[WB_K], pk_slb[WB_K], npk;
     __shared__ float pk_v[WB_K];
+    __shared__ __attribute__((aligned(16))) float fin_scr[WB_FIN_THREADS / 64][256]; // ward_sqdist_wave's scratch
     WB_TIMER(const unsigned long long tf0 = wall_clock64();)
+    WB_TIMER(if (threadIdx.x == 0 && st->B.dbg3[3] && st->B.dbg4[3] != ~0ull) {
+        st->B.dbg4[0] += st->B.dbg3[3] - st->B.dbg4[3]; /* first main start -> last main end */
+        st->B.dbg4[1] += tf0 - st->B.dbg3[3];           /* last main end -> finish start (new-row minima + launch gaps) */
+        st->B.dbg4[2] += st->B.dbg4[3] - st->B.dbg_t0;  /* preselection start -> first main start */
+        if (st->B.dbg5[0] > st->B.dbg_t0) st->B.dbg5[1] += st->B.dbg5[0] - st->B.dbg_t0; /* preselection start -> last spare workgroup's end */
+        if (st->B.dbg6[0] > st->B.dbg_t0) st->B.dbg6[1] += st->B.dbg6[0] - st->B.dbg_t0; /* preselection start -> last end of the spare phase A */
+        st->B.dbg6[0] = 0;
+        st->B.dbg5[0] = 0;
+        st->B.dbg3[3] = 0;
+        st->B.dbg4[3] = ~0ull;
+    })
     {
         constexpr int NW = (int)(sizeof(ward_state) / 4);
         static_assert(sizeof(ward_state) % 4 == 0, "snapshot by dwords");
@@ -2969,6 +3397,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             rowmin[b] = ICL_MAXF;
             rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
             rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
+            if (J != nbp && rf.rl_cnt) rf.rl_cnt[c] = 0; // the members of the picks that did not commit live on: the row's list does not cover them
         }
         if (full0 && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
             rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
@@ -3066,6 +3495,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.sb[j] = ls.B.pre_sb[j];
                         st->B.val[j] = ls.B.pre_val[j];
                         st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
+                        st->B.ub2[j] = 0x7f7fffffu; // MaxFloat32
+                        st->B.cand_n[j] = 0;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
                         rowoff[n + t1 + j] = ward_new_row(n, ld, t1 + j, t0, ls.B.a, merges, rowoff);
                     } else if (lane >= WB_K && lane < WB_K + np)
@@ -3383,7 +3814,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             int ri;
             {
                 const int noex[1] = {-1};
-                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf);
+                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf, &fin_scr[0][0]);
             }
             if (threadIdx.x == 0) {
                 rowmin[bi] = rv;
@@ -3422,6 +3853,8 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             st->B.sb[j] = pk_sb[j];
             st->B.val[j] = pk_v[j];
             st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
+            st->B.ub2[j] = 0x7f7fffffu;
+            st->B.cand_n[j] = 0;
             rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
             rowoff[n + t + j] = ward_new_row(n, ld, t + j, t0, ls.B.a, merges, rowoff);
         }
@@ -3523,8 +3956,11 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mu};
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mu, w->cand, w->rl_cnt, w->rl_col, w->rl_B};
         w->mu = nullptr;
+        w->cand = nullptr;
+        w->rl_cnt = w->rl_col = nullptr;
+        w->rl_B = nullptr;
         w->nrm = nullptr;
         w->colsum = nullptr;
         w->zero = nullptr;
@@ -3573,6 +4009,10 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(nrm, float, w->M); // by creation id (merged clusters: written by the update kernel's bound body)
         ICL_HIP(ctx, hipMemsetAsync(w->nrm, 0, (size_t)w->M * sizeof(float), ctx->stream));
         WS_ALLOC(mu, float, w->cn_stride);
+        WS_ALLOC(cand, int32_t, WB_K * WB_CAND_CAP);
+        WS_ALLOC(rl_cnt, int32_t, w->M);
+        WS_ALLOC(rl_B, float, w->M);
+        WS_ALLOC(rl_col, int32_t, w->M * WB_RL);
         WS_ALLOC(colsum, double, dd);
         WS_ALLOC(zero, char, 256);
         ICL_HIP(ctx, hipMemsetAsync(w->zero, 0, 256, ctx->stream));
@@ -3856,7 +4296,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // Exact mode, the rows this call computes itself: by default PROVEN LOWER BOUNDS from the matrix cores, made exact on demand by
     // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
     // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
-    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f};
+    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f, nullptr, nullptr, nullptr};
     struct free_guard {
         void *p = nullptr;
         ~free_guard() { if (p) (void)hipFree(p); }
@@ -3871,7 +4311,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const double u = 5.9604644775390625e-08; // 2^-24
         const double gD = K * u / (1.0 - K * u), gp = std::pow(1.0 + u, d + 2) - 1.0;
         rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)),
-                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f};
+                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f, nullptr, nullptr, nullptr};
         {
             // pairs with a merged member (the update kernel's bound body): chains of at most Dm products (the ring's whole stages) and the
             // sums of the two k halves / two accumulators; the merged clusters' norms come from the same kind of chain:
@@ -3968,11 +4408,10 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             w->wx_attr = true;
         }
-        // Bound body of the update kernel (rows of the new clusters as lower bounds from the matrix cores): whenever the matrix holds
-        // bounds anyway, the shape fits (whole k-groups; ring + centring vector + static arrays inside the CU's 160 KB) and
-        // icl_set_ward_options has not asked for exact rows (ICL_DIST_BOUND_INIT)
+        // Bound body of the update kernel (rows of the new clusters as lower bounds from the matrix cores): when icl_set_ward_options
+        // asks for it (ICL_DIST_BOUND) and the shape fits (whole k-groups; ring + centring vector + static arrays inside the CU's 160 KB)
         const size_t wxb_lds_bytes = wx_lds_bytes + (size_t)((dqb + WX_SG - 1) / WX_SG * WX_SG) * 16;
-        bool upd_bound = !lw && rf.E && (d & 3) == 0 && ctx->ward_dist != 3;
+        bool upd_bound = !lw && rf.E && (d & 3) == 0 && ctx->ward_dist == 2; // measured slower end to end than the exact rows at N = 100 000 and 250 000: on request only
         if (upd_bound) {
             hipFuncAttributes fa;
             ICL_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)ward_update_batch2_kernel<true>));
@@ -3983,7 +4422,13 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
         }
         rf.upd = upd_bound ? 1 : 0;
-        const wx_bound_args wba{w->mu, w->nrm};
+        if (upd_bound) {
+            rf.rl_cnt = w->rl_cnt;
+            rf.rl_B = w->rl_B;
+            rf.rl_col = w->rl_col;
+            ICL_HIP(ctx, hipMemsetAsync(w->rl_cnt, 0, (size_t)w->M * sizeof(int32_t), ctx->stream));
+        }
+        const wx_bound_args wba{w->mu, w->nrm, w->cand};
         // the express step's data phase runs in ward_finish_data_kernel from a record the finish kernel leaves behind cnewI
         int32_t *fdrec = (!lw && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
@@ -4008,7 +4453,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                                    w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st,
                                    max_size, n, w->rowmin, w->rownn, rf, wba);
                 hipLaunchKernelGGL(ward_newrow_min_kernel, dim3(WB_K), dim3(1024), 0, ctx->stream, n, w->cnew, w->cn_stride, w->rowoff, w->msz, w->mcid, w->Dtri,
-                                   w->st, max_size, rf);
+                                   w->st, max_size, rf, w->cand, w->mcol);
                 return;
             }
             hipLaunchKernelGGL(ward_update_batch2_kernel<false>, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
@@ -4114,12 +4559,27 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (batched && getenv("ICL_WARD_STATS") && rf.E)
         fprintf(stderr, "[icl] distance bounds in the merge loop: %llu scans of singleton rows, %llu collecting passes, %llu evaluation rounds, %llu entries evaluated\n",
                 hst.B.rf_stat[0], hst.B.rf_stat[1], hst.B.rf_stat[2], hst.B.rf_stat[3]);
+    if (batched && getenv("ICL_WARD_STATS") && rf.upd)
+        fprintf(stderr, "[icl] scans of merged clusters' rows: %llu with a nearest-neighbour list, %llu answered by it; %llu without a list\n", hst.B.rf_stat[8], hst.B.rf_stat[9], hst.B.rf_stat[10]);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] rows of new clusters: %s\n", rf.upd ? "lower bounds from the matrix cores + exact minima (bound body)" : lw ? "Lance-Williams" : "exact values (vector ALUs)");
     if (batched && getenv("ICL_WARD_STATS") && rf.E)
         fprintf(stderr, "[icl] distance bounds, initial row minima: %llu rows, %llu evaluation rounds, %llu entries evaluated (%.2f %% of the pairs)\n",
                 hst.B.rf_stat[4], hst.B.rf_stat[6], hst.B.rf_stat[7], 100.0 * (double)hst.B.rf_stat[7] / (0.5 * (double)n * (double)(n - 1)));
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
 #ifdef ICL_WARD_TIMERS
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] bound body, per step us: first main start -> last main end %.1f; last main end -> finish start %.1f; preselection start -> first main start %.1f\n",
+                hst.B.dbg4[0] * 0.01 / hst.B.steps, hst.B.dbg4[1] * 0.01 / hst.B.steps, (double)(long long)hst.B.dbg4[2] * 0.01 / hst.B.steps);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] preselection start -> last spare workgroup's end, per step us: %.1f (phase A done at %.1f); spare rescans: %llu singleton rows, %.1f us each; %llu merged rows, %.1f us each; longest %.1f us\n",
+                hst.B.dbg5[1] * 0.01 / hst.B.steps, hst.B.dbg6[1] * 0.01 / hst.B.steps, hst.B.dbg6[3], hst.B.dbg6[2] * 0.01 / (hst.B.dbg6[3] ? hst.B.dbg6[3] : 1),
+                hst.B.dbg6[5], hst.B.dbg6[4] * 0.01 / (hst.B.dbg6[5] ? hst.B.dbg6[5] : 1), hst.B.dbg6[6] * 0.01);
+    if (batched && getenv("ICL_WARD_STATS"))
+        fprintf(stderr, "[icl] new-row minima, row 0, per step us: list filtered %.1f, done %.1f; bound body, first main workgroup: %.2f blocks per step, stage loop %.1f us, epilogue %.1f us per block\n",
+                hst.B.dbg2[1] * 0.01 / hst.B.steps, hst.B.dbg2[2] * 0.01 / hst.B.steps, (double)hst.B.dbg3[2] / hst.B.steps,
+                hst.B.dbg3[0] * 0.01 / (hst.B.dbg3[2] ? hst.B.dbg3[2] : 1), hst.B.dbg3[1] * 0.01 / (hst.B.dbg3[2] ? hst.B.dbg3[2] : 1));
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
                 hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,

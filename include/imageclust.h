@@ -186,10 +186,12 @@ int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int
 /* How the exact mode builds ComputeInitialDistanceMatrix (clustering.go:61-73).  ICL_DIST_EXACT: every value by the exact
  * vector-ALU kernel (3 D unfused fp32 ops per pair).  ICL_DIST_BOUND: proven lower bounds from an f32 GEMM on the matrix cores,
  * each entry evaluated exactly (the reference's own expression) only when a row scan finds it near the row's minimum -- the same
- * cluster ids, member order, merge log and merge values, bit for bit.  With bounds in the matrix, UpdateDistanceMatrix's new rows
- * (clustering.go:75-108) are written as bounds too (16 new clusters x 16 live clusters per matrix-core instruction) and their
- * minima found by exact evaluation of the entries in the minimum's band; ICL_DIST_BOUND_INIT keeps the new rows on the exact
- * vector-ALU kernel (bounds in the initial matrix only).  ICL_DIST_AUTO (default): bounds for n >= 4096. */
+ * cluster ids, member order, merge log and merge values, bit for bit.  ICL_DIST_BOUND_INIT: bounds in the initial matrix,
+ * UpdateDistanceMatrix's new rows (clustering.go:75-108) as values from the exact vector-ALU kernel.  ICL_DIST_BOUND: the new rows
+ * as bounds too (16 new clusters x 16 live clusters per matrix-core instruction), their minima by exact evaluation of the entries
+ * in the minimum's band -- the update kernel becomes HBM-bound, but the exact minima and the row re-scans it leaves behind cost more
+ * than it saves at N = 100 000 .. 250 000, so it runs on request only.  ICL_DIST_AUTO (default): ICL_DIST_BOUND_INIT
+ * for n >= 4096, ICL_DIST_EXACT below. */
 enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3 };
 int icl_set_ward_options(icl_ctx *ctx, int dist_mode);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position

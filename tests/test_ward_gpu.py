@@ -294,6 +294,14 @@ def test_large_n_creation_ids_past_40960(ctx):
     log and every merge value must equal the oracle's."""
     f = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
     assert f["merges"] == 21360 and 24000 + f["merges"] > 40960
+    # the same run with the new clusters' rows as lower bounds from the matrix cores (ICL_DIST_BOUND: candidate lists, exact minima by
+    # ward_newrow_min_kernel, nearest-neighbour lists of the merged rows): same ids, member order, merge log and values
+    ctx.set_ward_options(2)
+    try:
+        g = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
+    finally:
+        ctx.set_ward_options(0)
+    assert g["merges"] == 21360
 
 
 def test_large_n_creation_ids_past_65536(ctx):
@@ -367,6 +375,12 @@ def test_config2_full_size_two_pipelines_agree_100k(ctx):
 
     args = (100000, 2048, 20250218, 5, 50)
     mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
+    ctx.set_ward_options(2)  # ... and a third one: the new clusters' rows as lower bounds from the matrix cores (ICL_DIST_BOUND)
+    try:
+        bound = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
+    finally:
+        ctx.set_ward_options(0)
+    assert bound == mine
     env = dict(os.environ, ICL_WARD_BATCH="0", ICL_CHILD_DIST="1")  # the witness also builds every initial distance with the exact kernel
     p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), *map(str, args)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
