@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--prec", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: bf16 MFMA with fp32 accumulate (BASELINE.json configs[1], the default); fp32: f32 MFMA, the parity "
                          "path whose embeddings meet 1e-4 against the fp32 restatement (157.3 TFLOP/s matrix peak)")
-    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound", "bound-init", "cut"], default="auto",
+    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound", "bound-init"], default="auto",
                     help="exact mode only (include/imageclust.h ICL_DIST_*): how distances are produced -- every value on the vector ALUs, "
                          "or proven lower bounds from the matrix cores with exact evaluation on demand (same ids, bit for bit); "
                          "bound-init keeps UpdateDistanceMatrix's new rows on the exact kernel; auto: bounds for n >= 4096")
@@ -173,7 +173,7 @@ def main():
     from imageclust_amd import distributed as D
 
     ctx = _lib.Context(local_rank)
-    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2, "bound-init": 3, "cut": 4}[args.ward_dist])
+    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2, "bound-init": 3}[args.ward_dist])
     ctx.load_synthetic(1)
     ctx.set_batch(args.batch)
     if args.scaling == "weak":

@@ -506,7 +506,6 @@ struct wrefine {
     int32_t *rl_cnt;
     float *rl_B;
     int32_t *rl_col;         // [creation id][WB_RL]
-    float cutm;              // early cut of the exact rows (upd == 2): a chain wave stops above (1 + cutm) x the row's best value
 };
 #define WB_RL 16
 __device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
@@ -515,7 +514,6 @@ __device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf, fl
 {
     // R <= (T + E_ab)(1 + g') w2,  w2 (T - E_ab) <= L (1 + 2 g')  (the store rounded L down by at most g' + 1e-6 relative):
     // R <= (L (1 + 2 g') + 2 w2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
-    if (merged && rf.upd == 2) return ICL_MAXF; // a partial sum (early cut of the exact rows) says nothing about how large the value is
     const float g = merged ? rf.gam_m : rf.gam, ce = merged ? rf.ceps_m : rf.ceps;
     return (L * (1.0f + 3.0f * g) + 2.0001f * (w2 * ce) * ns) * (1.0f + 2.0f * g);
 }
@@ -2288,7 +2286,6 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
 #define WB_CAND_CAP 4096 /* columns a new row's candidate list holds (more: ward_newrow_min_kernel scans the row) */
 #define WB_LCAP 48       /* ... a workgroup collects per row before it appends to the global list directly */
 #define WB_NR_CAP 512    /* candidates ward_newrow_min_kernel ranks (more: it scans the row) */
-#define WB_CUT_MARGIN 1.0f /* early cut of the exact rows: a chain wave stops once all its entries stand above (1 + margin) x the row's best value */
 #define WB_LMARGIN 0.04f /* candidates are collected up to (1 + margin) x the threshold: ~16 nearest neighbours per row at N = 100 000 ResNet embeddings */
 struct wx_bound_args {
     const float *mu;  // [>= 4 (dqp + WX_SG)] the centring vector of the distance bounds, zero padded
@@ -2675,13 +2672,6 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
     // points of the stage loop, so each wait finds its data already there.  Drawn on the spot, the same chain cost every block
     // ~5 us (two workgroup barriers around a device atomic) + ~4 us of dependent loads: a quarter of the block's 46 us.
     __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_mx[2][64], nx_dirty[2][64];
-    // EARLY CUT (rf.upd == 2): the running sums only grow (every term is a square), and fl(w * s) grows with s, so the Ward value of
-    // a partial sum is a proven LOWER BOUND of the entry's value.  Once every live lane of a chain wave stands above (1 + margin) x
-    // the smallest VALUE the row has produced so far anywhere on the device (st->B.ub2, among the clusters that survive the batch),
-    // none of its entries can be or tie the row's minimum: the wave stops, and its entries are stored as flagged bounds that later
-    // row scans evaluate if they ever need them (scan_row_min).  ubc_l: the thresholds as last seen (they only fall: stale = cautious).
-    __shared__ float ubc_l[WB_K];
-    const bool cut_on = rf.upd == 2 && !virt;
     const int nmain = (int)gridDim.x - (WB_R + 2); // persistent main workgroups
     int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_mx = 0, pf_dirty = 0; // chain wave 0 only
     auto pf_advance = [&](const int upto, const int par) {
@@ -2731,11 +2721,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
     const int64_t mblk = virt ? (blk_it == 0 ? 0 : -1) : __builtin_amdgcn_readfirstlane(nx_blk[par]); // (an LDS read: tell hipcc it is wave-uniform)
     rp = __builtin_amdgcn_readfirstlane(rp);
     pf_done = 0;
-    if (mblk < 0 || (!virt && mblk * 64 >= nlive)) {
-        WB_TIMER(if (threadIdx.x == 0 && !virt) atomicMax(&st->B.dbg3[3], wall_clock64());)
-        WB_TIMER(if (threadIdx.x == 0 && !virt) atomicMin(&st->B.dbg4[3], tm0);)
-        break;
-    }
+    if (mblk < 0 || (!virt && mblk * 64 >= nlive)) break;
     const int dq_real = d >> 2;
     // ---- part 1: what the loaders need (slot, dirty columns) -- then the ring's first stages are requested BEFORE the
     // dependent slot_id -> asz loads of part 2, which resolve while the DMA is in flight
@@ -2828,18 +2814,6 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
     }
     const int jA = __builtin_amdgcn_readfirstlane(wave < WX_CW ? wave * 2 : 0); // this chain wave's pair of tentative merges: jA, jA + 1
     const bool chain = wave < WX_CW && jA < nb;
-    if (cut_on && wave == WX_CW && lane < WB_K) // (a loader wave; the stage barriers order this against the chain waves' reads)
-        ubc_l[lane] = __uint_as_float(__hip_atomic_load(&st->B.ub2[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    // the Ward factors of this lane's two entries (clustering.go:142-144), for the cut test and the epilogue alike
-    float wqA = 0.0f, wqB = 0.0f;
-    bool okA = false, okB = false, cut = false;
-    if (chain) {
-        okA = (okmask >> jA) & 1u;
-        okB = jA + 1 < nb && ((okmask >> (jA + 1)) & 1u);
-        const int scA = psc[jA], scB = psc[(jA + 1) & (WB_K - 1)];
-        wqA = (float)((int64_t)sx * (int64_t)scA) / (float)(sx + scA);
-        wqB = (float)((int64_t)sx * (int64_t)scB) / (float)(sx + scB);
-    }
     f2 sP = f2{0.0f, 0.0f}; // {sA, sB}: the pair's running sums as one packed register pair
     // one quarter stage (4 k-groups) of the wave's two chains.
     // (Measured and dropped: an explicit two-register-set software pipeline across quarters -- reads of quarter q+1 issued before
@@ -2907,13 +2881,8 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                 issue(i + WX_R - 1, rp, slot, dirty_lane); // into the slot stage i-1 was read from: every chain wave is past this barrier
             else if (nxt_on) // the ring runs on into the next block (its stage 0 sits in slot rp + nstage)
                 issue(i + WX_R - 1 - nstage, rp + nstage, (int64_t)nxt_blk * 64 + lane, nxt_dirty);
-        } else if (chain && !cut) {
+        } else if (chain) {
             consume(i);
-            if (cut_on && i >= 1 && i + 1 < nstage) {
-                const float tA = ubc_l[jA], tB = ubc_l[(jA + 1) & (WB_K - 1)];
-                const bool over = (!okA || wqA * sP.x > tA * (1.0f + rf.cutm)) && (!okB || wqB * sP.y > tB * (1.0f + rf.cutm));
-                cut = __all(over); // (NaN compares false: such a wave never stops; MaxFloat32 thresholds -- no value yet -- neither)
-            }
         }
     }
     if (wave == 0 && !virt) pf_advance(4, par ^ 1); // few stages (small D): finish the hand-over now
@@ -2928,11 +2897,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         const int64_t ro = ro_l[j];
         unsigned long long key = ~0ull, key2 = ~0ull;
         const float s = cc ? sP.y : sP.x;
-        if (((okmask >> j) & 1u) && cut) {
-            // a partial sum: the entry is stored as a lower bound (sign bit set), not a value; it takes no part in the row's minimum
-            const float L = (cc ? wqB : wqA) * s;
-            Dtri[ro + mx] = __uint_as_float(__float_as_uint(L >= 0.0f ? L : 0.0f) | 0x80000000u);
-        } else if ((okmask >> j) & 1u) {
+        if ((okmask >> j) & 1u) {
             const float num = (float)((int64_t)sx * (int64_t)sc);
             const float den = (float)(sx + sc);
             const float val = (num / den) * s;
@@ -2949,10 +2914,6 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         key2 = wave_umin64(key2);
         if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
         if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
-        if (cut_on && lane == 0 && key2 != ~0ull && __uint_as_float((unsigned)(key2 >> 32)) < ubc_l[j]) { // the row's threshold falls
-            atomicMin(&st->B.ub2[j], (unsigned)(key2 >> 32));
-            ubc_l[j] = __uint_as_float((unsigned)(key2 >> 32));
-        }
         WB_TIMER(if (lane == 0 && j == 0 && mblk == 0 && !virt) st->B.dbg[1] += wall_clock64() - tm0;)
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
@@ -4335,7 +4296,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // Exact mode, the rows this call computes itself: by default PROVEN LOWER BOUNDS from the matrix cores, made exact on demand by
     // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
     // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
-    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f, nullptr, nullptr, nullptr, 0.0f};
+    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f, nullptr, nullptr, nullptr};
     struct free_guard {
         void *p = nullptr;
         ~free_guard() { if (p) (void)hipFree(p); }
@@ -4350,7 +4311,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const double u = 5.9604644775390625e-08; // 2^-24
         const double gD = K * u / (1.0 - K * u), gp = std::pow(1.0 + u, d + 2) - 1.0;
         rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)),
-                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f, nullptr, nullptr, nullptr, getenv("ICL_WARD_CUT_MARGIN") ? (float)atof(getenv("ICL_WARD_CUT_MARGIN")) : WB_CUT_MARGIN};
+                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f, nullptr, nullptr, nullptr};
         {
             // pairs with a merged member (the update kernel's bound body): chains of at most Dm products (the ring's whole stages) and the
             // sums of the two k halves / two accumulators; the merged clusters' norms come from the same kind of chain:
@@ -4460,7 +4421,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                 w->wxb_attr = wxb_lds_bytes;
             }
         }
-        rf.upd = upd_bound ? 1 : (!lw && rf.E && (d & 3) == 0 && ctx->ward_dist == 4) ? 2 : 0; // 2: exact rows with the early cut (ICL_DIST_CUT; on request: slower end to end)
+        rf.upd = upd_bound ? 1 : 0;
         if (upd_bound) {
             rf.rl_cnt = w->rl_cnt;
             rf.rl_B = w->rl_B;
@@ -4511,7 +4472,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         };
         finish_b(); // first batch: one pick by the plain lazy selection
         const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : upd_bound ? 4 : 2 + 8 * rf.upd) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : upd_bound ? 4 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -4522,7 +4483,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = lw ? 3 : upd_bound ? 4 : 2 + 8 * rf.upd;
+            w->graph_lw = lw ? 3 : upd_bound ? 4 : 2;
             w->graph_E = rf.E;
             w->graph_ceps = rf.ceps;
         }
@@ -4601,7 +4562,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (batched && getenv("ICL_WARD_STATS") && rf.upd)
         fprintf(stderr, "[icl] scans of merged clusters' rows: %llu with a nearest-neighbour list, %llu answered by it; %llu without a list\n", hst.B.rf_stat[8], hst.B.rf_stat[9], hst.B.rf_stat[10]);
     if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] rows of new clusters: %s\n", rf.upd == 2 ? "exact values, chains cut early where the row's minimum is out of reach" : rf.upd ? "lower bounds from the matrix cores + exact minima (bound body)" : lw ? "Lance-Williams" : "exact values (vector ALUs)");
+        fprintf(stderr, "[icl] rows of new clusters: %s\n", rf.upd ? "lower bounds from the matrix cores + exact minima (bound body)" : lw ? "Lance-Williams" : "exact values (vector ALUs)");
     if (batched && getenv("ICL_WARD_STATS") && rf.E)
         fprintf(stderr, "[icl] distance bounds, initial row minima: %llu rows, %llu evaluation rounds, %llu entries evaluated (%.2f %% of the pairs)\n",
                 hst.B.rf_stat[4], hst.B.rf_stat[6], hst.B.rf_stat[7], 100.0 * (double)hst.B.rf_stat[7] / (0.5 * (double)n * (double)(n - 1)));
@@ -4798,7 +4759,7 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
 
 extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
 {
-    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_CUT) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
+    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_BOUND_INIT) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->ward_dist = dist_mode;
     return ICL_OK;

@@ -190,11 +190,9 @@ int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int
  * UpdateDistanceMatrix's new rows (clustering.go:75-108) as values from the exact vector-ALU kernel.  ICL_DIST_BOUND: the new rows
  * as bounds too (16 new clusters x 16 live clusters per matrix-core instruction), their minima by exact evaluation of the entries
  * in the minimum's band -- the update kernel becomes HBM-bound, but the exact minima and the row re-scans it leaves behind cost more
- * than it saves at N = 100 000 .. 250 000, so it runs on request only.  ICL_DIST_CUT: ICL_DIST_BOUND_INIT with the
- * exact kernel's chains stopped early where a row's minimum is out of reach (the partial sum is stored as the entry's lower bound);
- * also slower end to end, on request only.  ICL_DIST_AUTO (default): ICL_DIST_BOUND_INIT for n >= 4096, ICL_DIST_EXACT below.
- * Every mode returns the same cluster ids, member order, merge log and merge values. */
-enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3, ICL_DIST_CUT = 4 };
+ * than it saves at N = 100 000 .. 250 000, so it runs on request only.  ICL_DIST_AUTO (default): ICL_DIST_BOUND_INIT
+ * for n >= 4096, ICL_DIST_EXACT below. */
+enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3 };
 int icl_set_ward_options(icl_ctx *ctx, int dist_mode);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
  * cluster, creation id of the lower-position one); returns the number of merges performed. */

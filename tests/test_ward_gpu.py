@@ -256,17 +256,16 @@ def test_distance_bounds_mode_on_every_small_case(ctx):
     """ICL_DIST_BOUND forced on the small suite (auto mode only uses it from n = 4096): the initial matrix holds proven lower
     bounds from the f32 MFMA GEMM and entries are evaluated exactly on demand by the row scans -- ties, duplicates, NaN / Inf,
     tight constraints, D not a multiple of 4 or 32, D > 2048.  Ids, member order, merge log and every merge value against both oracles."""
-    for mode in (2, 4):  # 4: ICL_DIST_CUT, what auto mode runs from n = 4096 (bounds in the initial matrix, exact new rows with the early cut)
-        ctx.set_ward_options(mode)
-        try:
-            for name, E, mn, mx in WC.small_cases():
-                try:
-                    same_as_oracle(ctx, E, mn, mx)
-                    same_as_fast_oracle(ctx, E, mn, mx)
-                except AssertionError as e:
-                    raise AssertionError("mode %d, %s: %s" % (mode, name, e))
-        finally:
-            ctx.set_ward_options(0)
+    ctx.set_ward_options(2)
+    try:
+        for name, E, mn, mx in WC.small_cases():
+            try:
+                same_as_oracle(ctx, E, mn, mx)
+                same_as_fast_oracle(ctx, E, mn, mx)
+            except AssertionError as e:
+                raise AssertionError("%s: %s" % (name, e))
+    finally:
+        ctx.set_ward_options(0)
 
 
 def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
@@ -278,7 +277,7 @@ def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
     E1 = (cen[rng.integers(0, 300, 6000)] * (1 + 1e-6 * rng.standard_normal((6000, 1)))).astype(np.float32)
     for E, mn, mx in [(E1, 5, 50), (WC.ties(5000, 5, 9, levels=6), 2, 30)]:
         res = []
-        for mode in (1, 2, 3, 4):  # exact everywhere / bounds in the initial matrix and the new rows / in the initial matrix only / ... + early cut of the new rows
+        for mode in (1, 2, 3):  # exact everywhere / bounds in the initial matrix and the new rows / in the initial matrix only
             ctx.set_ward_options(mode)
             cid, rank, nc = ctx.cluster(E, mn, mx)
             res.append((cid.copy(), rank.copy(), nc, ctx.last_merges().copy(), ctx.last_merge_values().copy()))
