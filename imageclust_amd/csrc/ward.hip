@@ -51,9 +51,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_TIMER(stmt)
 #endif
 #define WB_K 16 /* merges attempted per batched step (a power of two: lane-indexed tables): N=100k takes 15.6 merges per step */
-#define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch */
-#define WB_RM 4 /* rows each of them takes (matches wg, wg + WB_R, ...): hub clusters leave hundreds of rows dirty */
-#define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 192 are re-minimised per step; the rest stays lazy) */
+#ifndef WB_R
+#define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch (<= 64: one lane each in their flag barrier) */
+#endif
+#ifndef WB_RM
+#define WB_RM 2 /* rows each of them takes (matches wg, wg + WB_R, ...); the rest stays lazy.  Round 3 (a re-scan now reads three streams and the spare
+                   workgroups hold 50 CUs while they run): 48 x 2 -> merge loop 1 370 ms at N=100k, 48 x 4 1 391, 64 x 2 1 400, 64 x 3 1 409, 32 x 4 1 470 */
+#endif
+#define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 96 are re-minimised per step; the rest stays lazy) */
 #define WB_WTOP 5    /* keys a wave / a slice reports before its sentinel */
 #define WB_PA_KEYS (WB_WTOP + 1)
 struct ward_batch_state {
