@@ -340,7 +340,8 @@ def main():
                          "unit": "TFLOP/s" if exact else "GB/s",
                          "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
                          "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
-                         "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note),
+                         "traffic_note": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note)) if pmc_file else
+                                         "PMC passes were taken at the default workload (100 000 images, bf16) only",
                          "launches": upd["launches"],
                          "avg_launch_us": round(upd["ms"] * 1e3 / upd["launches"], 2),
                          "algorithmic_bytes_per_launch": round(upd["bytes"] / upd["launches"], 0),

@@ -54,6 +54,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef WB_R
 #define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch (<= 64: one lane each in their flag barrier) */
 #endif
+#ifndef WB_SCAN_U
+#define WB_SCAN_U 4 /* 16-byte loads of each of a row scan's three streams (values, sizes, ids) a lane keeps in flight */
+#endif
 #ifndef WB_RM
 #define WB_RM 2 /* rows each of them takes (matches wg, wg + WB_R, ...); the rest stays lazy.  Round 3 (a re-scan now reads three streams and the spare
                    workgroups hold 50 CUs while they run): 48 x 2 -> merge loop 1 370 ms at N=100k, 48 x 4 1 391, 64 x 2 1 400, 64 x 3 1 409, 32 x 4 1 470 */
@@ -458,11 +461,11 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
         }
     };
     const int64_t nvec = len >> 2;
-    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
-        float4 v[4];
-        int4 m[4], c[4];
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+        float4 v[WB_SCAN_U];
+        int4 m[WB_SCAN_U], c[WB_SCAN_U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WB_SCAN_U; ++j) {
             const int64_t q = q0 + (int64_t)j * blockDim.x;
             const bool has = q < nvec;
             v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
@@ -470,7 +473,7 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
             c[j] = has ? reinterpret_cast<const int4 *>(mcid)[q] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WB_SCAN_U; ++j) {
             visit(v[j].x, m[j].x, c[j].x);
             visit(v[j].y, m[j].y, c[j].y);
             visit(v[j].z, m[j].z, c[j].z);
@@ -664,11 +667,11 @@ template <typename F>
 __device__ __forceinline__ void ward_row_visit(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid, F &&f)
 {
     const int64_t nvec = len >> 2;
-    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
-        float4 v[4];
-        int4 m[4], c[4];
+    for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+        float4 v[WB_SCAN_U];
+        int4 m[WB_SCAN_U], c[WB_SCAN_U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WB_SCAN_U; ++j) {
             const int64_t q = q0 + (int64_t)j * blockDim.x;
             const bool has = q < nvec;
             v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
@@ -676,7 +679,7 @@ __device__ __forceinline__ void ward_row_visit(const float *__restrict__ row, in
             c[j] = has ? reinterpret_cast<const int4 *>(mcid)[q] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WB_SCAN_U; ++j) {
             const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
             f(v[j].x, m[j].x, c[j].x, col);
             f(v[j].y, m[j].y, c[j].y, col + 1);

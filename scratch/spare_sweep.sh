@@ -1,7 +1,7 @@
 #!/bin/bash
-# spare-workgroup sweep (WB_R workgroups x WB_RM rows each) at the metric's size: builds in scratch/so/
+# build-variant sweep at the metric's size: shared objects in scratch/so/lib_<tag>.so
 cp imageclust_amd/libimageclust_hip.so /tmp/lib_keep.so
-for v in R48_RM4 R48_RM2 R64_RM2 R64_RM3 R32_RM4; do
+for v in "$@"; do
   cp scratch/so/lib_$v.so imageclust_amd/libimageclust_hip.so
   timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ss.json 2> gpurun_out/ss.err || { tail -c 800 gpurun_out/ss.err; break; }
   python3 -c "
