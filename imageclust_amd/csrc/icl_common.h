@@ -143,3 +143,17 @@ __host__ __device__ static inline uint8_t icl_synth_pixel(uint64_t seed, int64_t
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     return (uint8_t)v;
 }
+
+// No C++ exception crosses the C ABI: entry points that allocate host memory (std::vector, std::string, std::thread) run their body
+// through this guard.
+template <typename F>
+static int no_throw(icl_ctx *ctx, const char *what, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return icl_fail(ctx, ICL_ERR_NOMEM, "%s: out of host memory", what);
+    } catch (...) {
+        return icl_fail(ctx, ICL_ERR_IO, "%s: unexpected failure", what);
+    }
+}

@@ -23,6 +23,7 @@ struct icl_group {
     std::mutex mu;
 };
 
+#define ICL_GROUP_MAX 64 /* contexts of a group (icl_group_create checks) */
 static int group_fail(icl_group *g, int code, const std::string &msg)
 {
     if (g) {
@@ -31,10 +32,25 @@ static int group_fail(icl_group *g, int code, const std::string &msg)
     }
     return code;
 }
+// the group's entry points build strings, vectors and threads: nothing of that may throw across the C ABI
+template <typename F>
+static int group_no_throw(icl_group *g, const char *what, F &&body)
+{
+    try {
+        return body();
+    } catch (...) {
+        if (g) {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->err.clear(); // (no allocation)
+        }
+        icl_fail(nullptr, ICL_ERR_NOMEM, "%s: out of host memory", what);
+        return ICL_ERR_NOMEM;
+    }
+}
 
 extern "C" int icl_group_create(const int32_t *devices, int32_t ndev, icl_group **out)
 {
-    if (!devices || ndev < 1 || ndev > 64 || !out) return icl_fail(nullptr, ICL_ERR_ARG, "icl_group_create: bad argument");
+    if (!devices || ndev < 1 || ndev > ICL_GROUP_MAX || !out) return icl_fail(nullptr, ICL_ERR_ARG, "icl_group_create: bad argument");
     icl_group *g = new (std::nothrow) icl_group();
     if (!g) return icl_fail(nullptr, ICL_ERR_NOMEM, "icl_group_create: out of memory");
     for (int i = 0; i < ndev; ++i) {
@@ -45,7 +61,14 @@ extern "C" int icl_group_create(const int32_t *devices, int32_t ndev, icl_group 
             delete g;
             return rc; // icl_create left its message in the thread-local error string
         }
-        g->ctx.push_back(c);
+        try {
+            g->ctx.push_back(c);
+        } catch (...) {
+            icl_destroy(c);
+            for (icl_ctx *p : g->ctx) icl_destroy(p);
+            delete g;
+            return icl_fail(nullptr, ICL_ERR_NOMEM, "icl_group_create: out of memory");
+        }
     }
     // peer access between distinct devices (xGMI inside a node); failure is not fatal: copies then stage through the host
     for (int i = 0; i < ndev; ++i)
@@ -76,10 +99,11 @@ template <typename F>
 static int for_each_ctx(icl_group *g, F &&f)
 {
     const int n = (int)g->ctx.size();
-    std::vector<int> rc((size_t)n, ICL_OK);
+    int rc[ICL_GROUP_MAX];
+    for (int i = 0; i < n; ++i) rc[i] = ICL_OK;
     std::vector<std::thread> th;
     try {
-        for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rc[(size_t)i] = f(i, g->ctx[(size_t)i]); });
+        for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = f(i, g->ctx[(size_t)i]); });
     } catch (...) {
         for (auto &t : th) t.join();
         return group_fail(g, ICL_ERR_NOMEM, "could not start a host thread per GPU");
@@ -87,24 +111,30 @@ static int for_each_ctx(icl_group *g, F &&f)
     rc[0] = f(0, g->ctx[0]);
     for (auto &t : th) t.join();
     for (int i = 0; i < n; ++i)
-        if (rc[(size_t)i] != ICL_OK) return group_fail(g, rc[(size_t)i], std::string("GPU ") + std::to_string(i) + ": " + icl_last_error(g->ctx[(size_t)i]));
+        if (rc[i] != ICL_OK) return group_fail(g, rc[i], std::string("GPU ") + std::to_string(i) + ": " + icl_last_error(g->ctx[(size_t)i]));
     return ICL_OK;
 }
 
 extern "C" int icl_group_load_synthetic(icl_group *g, uint64_t seed)
 {
+    return group_no_throw(g, "icl_group_load_synthetic", [&]() -> int {
     if (!g) return ICL_ERR_ARG;
     return for_each_ctx(g, [&](int, icl_ctx *c) { return icl_model_load_synthetic(c, seed); });
+    });
 }
 extern "C" int icl_group_load_onnx(icl_group *g, const char *path)
 {
+    return group_no_throw(g, "icl_group_load_onnx", [&]() -> int {
     if (!g || !path) return ICL_ERR_ARG;
     return for_each_ctx(g, [&](int, icl_ctx *c) { return icl_model_load_onnx(c, path); });
+    });
 }
 extern "C" int icl_group_load_blob(icl_group *g, const void *blob, int64_t bytes)
 {
+    return group_no_throw(g, "icl_group_load_blob", [&]() -> int {
     if (!g || !blob) return ICL_ERR_ARG;
     return for_each_ctx(g, [&](int, icl_ctx *c) { return icl_model_load_blob(c, blob, bytes); });
+    });
 }
 
 // contiguous index range of part i of n items over `parts` (the first n % parts parts hold one more)
@@ -117,6 +147,7 @@ static void shard_range(int64_t n, int parts, int i, int64_t &lo, int64_t &hi)
 
 extern "C" int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out)
 {
+    return group_no_throw(g, "icl_group_embed_u8", [&]() -> int {
     if (!g || n < 0 || (n && (!hwc_rgb || !out))) return group_fail(g, ICL_ERR_ARG, "icl_group_embed_u8: bad argument");
     const int parts = (int)g->ctx.size();
     return for_each_ctx(g, [&](int i, icl_ctx *c) {
@@ -124,6 +155,7 @@ extern "C" int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t 
         shard_range(n, parts, i, lo, hi);
         if (hi == lo) return (int)ICL_OK;
         return icl_embed_u8(c, hwc_rgb + lo * (int64_t)ICL_IMG_BYTES, hi - lo, head, prec, out + lo * head);
+    });
     });
 }
 
@@ -175,6 +207,7 @@ static int group_cluster_resident(icl_group *g, const std::vector<float *> &dE, 
 extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                  int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return group_no_throw(g, "icl_group_cluster", [&]() -> int {
     if (!g || n < 0 || d < 0 || !n_clusters || (n && (!E || !cluster_id || !member_rank))) return group_fail(g, ICL_ERR_ARG, "icl_group_cluster: bad argument");
     const int parts = (int)g->ctx.size();
     icl_ctx *c0 = g->ctx[0];
@@ -208,6 +241,7 @@ extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_
     if (rc == ICL_OK) rc = group_cluster_resident(g, dE, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
     cleanup();
     return rc;
+    });
 }
 
 // workflow.go:84-94 in one call: createEmbeddings (the per-image GetImageEmbedding fan-out, :149-185) followed by
@@ -220,6 +254,7 @@ extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_
 extern "C" int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update,
                                        float *E_out, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return group_no_throw(g, "icl_group_embed_cluster", [&]() -> int {
     if (!g || n < 0 || !n_clusters || (n && (!hwc_rgb || !cluster_id || !member_rank))) return group_fail(g, ICL_ERR_ARG, "icl_group_embed_cluster: bad argument");
     const int parts = (int)g->ctx.size();
     const int32_t d = ICL_HEAD_POOLED;
@@ -295,4 +330,5 @@ extern "C" int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int
     }
     cleanup();
     return rc;
+    });
 }

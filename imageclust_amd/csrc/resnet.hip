@@ -1577,19 +1577,7 @@ static int read_image(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb,
 }
 
 // No C++ exception may cross the C ABI (cgo / ctypes would terminate the host process): the ingest entry points allocate
-// buffers whose sizes come from files.
-template <typename F>
-static int no_throw(icl_ctx *ctx, const char *what, F &&body)
-{
-    try {
-        return body();
-    } catch (const std::bad_alloc &) {
-        return icl_fail(ctx, ICL_ERR_NOMEM, "%s: out of host memory", what);
-    } catch (...) {
-        return icl_fail(ctx, ICL_ERR_IO, "%s: unexpected failure", what);
-    }
-}
-
+// buffers whose sizes come from files (no_throw: icl_common.h).
 extern "C" int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h)
 {
     if (!path || !w || !h) return icl_fail(nullptr, ICL_ERR_ARG, "icl_decode_image_file: bad argument");

@@ -4128,6 +4128,7 @@ extern "C" int icl_ward_distance_matrix_dev(icl_ctx *ctx, const float *d_C, cons
 extern "C" int icl_ward_distance_matrix(icl_ctx *ctx, const float *C, const int32_t *sizes, int64_t n, int32_t d, float *D,
                                         int64_t ld)
 {
+    return no_throw(ctx, "icl_ward_distance_matrix", [&]() -> int {
     if (!ctx || n < 0 || d < 0 || ld < n || (n && (!C || !D))) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_distance_matrix: bad argument");
     if (n == 0) return ICL_OK;
     float *dC = nullptr, *dD = nullptr;
@@ -4153,6 +4154,7 @@ extern "C" int icl_ward_distance_matrix(icl_ctx *ctx, const float *C, const int3
         if (dS) (void)hipFree(dS);
     }
     return rc;
+    });
 }
 
 static int find_closest_locked(icl_ctx *ctx, const float *d_D, int64_t n, int64_t ld, int64_t *i, int64_t *j)
@@ -4187,6 +4189,7 @@ extern "C" int icl_find_closest_dev(icl_ctx *ctx, const float *d_D, int64_t n, i
 
 extern "C" int icl_find_closest(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, int64_t *i, int64_t *j)
 {
+    return no_throw(ctx, "icl_find_closest", [&]() -> int {
     if (!ctx || n < 0 || ld < n || !i || !j || (n && !D)) return icl_fail(ctx, ICL_ERR_ARG, "icl_find_closest: bad argument");
     *i = -1;
     *j = -1;
@@ -4200,6 +4203,7 @@ extern "C" int icl_find_closest(icl_ctx *ctx, const float *D, int64_t n, int64_t
                              : icl_fail(ctx, ICL_ERR_HIP, "find_closest upload failed: %s", hipGetErrorString(e));
     (void)hipFree(dD);
     return rc;
+    });
 }
 
 // Build the reference's final cluster list from the merge log (clustering.go:265-280 and SURVEY.md 8a C11):
@@ -4666,6 +4670,7 @@ extern "C" int icl_ward_span(int64_t row_lo, int64_t row_hi, int64_t *float_off,
 // that span of the packed triangle.  row_lo must be a multiple of 128, row_hi a multiple of 128 or n.
 extern "C" int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int64_t row_lo, int64_t row_hi, float *d_span)
 {
+    return no_throw(ctx, "icl_ward_distance_rows_dev", [&]() -> int {
     if (!ctx || n < 0 || d < 0 || row_lo < 0 || row_hi < row_lo || row_hi > n || (n && !d_E) || (row_hi > row_lo && !d_span) || row_lo % DT_TILE ||
         (row_hi % DT_TILE && row_hi != n))
         return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_distance_rows_dev: bad argument (rows must be whole 128-row tile rows)");
@@ -4676,16 +4681,19 @@ extern "C" int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_
                                    icl_ceil_div(row_hi, DT_TILE)));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICL_OK;
+    });
 }
 
 // Allocates the clustering workspace for (n, d) and returns where rows [row_lo, row_hi) of the distance triangle live on this
 // GPU, so that a transport (RCCL recv, peer copy) can write another GPU's span straight into place.
 extern "C" int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d)
 {
+    return no_throw(ctx, "icl_ward_prepare", [&]() -> int {
     if (!ctx || n < 0 || d < 0) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_prepare: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
     return ward_ensure(ctx, n, d);
+    });
 }
 
 // Where rows [row_lo, row_hi) computed elsewhere are to be delivered on this GPU: a staging buffer in the transport format
@@ -4756,6 +4764,7 @@ extern "C" int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi
 extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                          int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return no_throw(ctx, "icl_cluster_prefilled_dev", [&]() -> int {
     if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!d_E || !cluster_id || !member_rank)))
         return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -4763,6 +4772,7 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
     if (!ctx->ward || ctx->ward->capN != n || ctx->ward->capD != d)
         return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: call icl_ward_prepare(n, d) and deposit the foreign rows first");
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, own_lo, own_hi);
+    });
 }
 
 extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
@@ -4776,11 +4786,13 @@ extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
 extern "C" int icl_cluster_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size,
                                int update, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return no_throw(ctx, "icl_cluster_dev", [&]() -> int {
     if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!d_E || !cluster_id || !member_rank)))
         return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_dev: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+    });
 }
 
 // workflow.go:84-94 on ONE GPU in one call: createEmbeddings (:149-185, here the batched forward passes over n resident images)
@@ -4793,6 +4805,7 @@ int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head
 extern "C" int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int prec, int32_t min_size, int32_t max_size, int update, int flags,
                                      float *d_E, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return no_throw(ctx, "icl_embed_cluster_dev", [&]() -> int {
     if (!ctx || n < 0 || !n_clusters || (n && (!d_img || !d_E || !cluster_id || !member_rank)))
         return icl_fail(ctx, ICL_ERR_ARG, "icl_embed_cluster_dev: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -4844,11 +4857,13 @@ extern "C" int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t
         return rc != ICL_OK ? rc : icl_fail(ctx, ICL_ERR_HIP, "icl_embed_cluster_dev: %s", hipGetErrorString(e));
     }
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, 0, 0); // every row is in place
+    });
 }
 
 extern "C" int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                            int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
+    return no_throw(ctx, "icl_cluster", [&]() -> int {
     if (!ctx || n < 0 || d < 0 || !n_clusters || (n && (!E || !cluster_id || !member_rank)))
         return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -4867,6 +4882,7 @@ extern "C" int icl_cluster(icl_ctx *ctx, const float *E, int64_t n, int32_t d, i
     int rc = cluster_locked(ctx, dE, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
     if (dE) (void)hipFree(dE);
     return rc;
+    });
 }
 
 __global__ void merge_centroid_kernel(const float *__restrict__ ca, float fa, const float *__restrict__ cb, float fb, float fs,
@@ -4949,6 +4965,7 @@ __global__ void udm_newrow_kernel(const float *__restrict__ C, const int32_t *__
 extern "C" int icl_update_distance_matrix(icl_ctx *ctx, const float *D, int64_t n, int64_t ld, const float *C, const int32_t *sizes, int32_t d,
                                           int64_t r1, int64_t r2, float *Dout, int64_t ldout)
 {
+    return no_throw(ctx, "icl_update_distance_matrix", [&]() -> int {
     if (!ctx || n < 2 || ld < n || ldout < n - 1 || d < 0 || !D || !Dout || !sizes || (d && !C) || r1 < 0 || r2 < 0 || r1 >= n || r2 >= n || r1 == r2)
         return icl_fail(ctx, ICL_ERR_ARG, "icl_update_distance_matrix: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -4974,6 +4991,7 @@ extern "C" int icl_update_distance_matrix(icl_ctx *ctx, const float *D, int64_t 
     ICL_HIP(ctx, hipMemcpy2DAsync(Dout, (size_t)ldout * 4, gO.p, (size_t)m1 * 4, (size_t)m1 * 4, (size_t)m1, hipMemcpyDeviceToHost, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICL_OK;
+    });
 }
 
 extern "C" int64_t icl_last_merge_values(icl_ctx *ctx, float *vals, int64_t cap)
