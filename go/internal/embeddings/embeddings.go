@@ -70,10 +70,8 @@ func LoadPretrainedModelONNX(modelPath string) (Net, error) {
 		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%v)", modelPath, err)
 	}
 	ctx := (*C.icl_ctx)(raw)
-	p := C.CString(modelPath)
-	defer C.free(unsafe.Pointer(p))
-	if rc := C.icl_model_load_onnx(ctx, p); rc != C.ICL_OK {
-		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%s)", modelPath, C.GoString(C.icl_last_error(ctx)))
+	if err := iclengine.LoadModelOnce(modelPath); err != nil { // a repeated load of the same file is a no-op
+		return Net{}, fmt.Errorf("failed to load ResNet50 ONNX model from: %s (%v)", modelPath, err)
 	}
 	return Net{ctx: ctx}, nil
 }

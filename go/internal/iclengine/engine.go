@@ -6,6 +6,7 @@ package iclengine
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../../imageclust_amd -limageclust_hip
+#include <stdlib.h>
 #include "imageclust.h"
 */
 import "C"
@@ -41,6 +42,32 @@ func Ctx() (unsafe.Pointer, error) {
 		}
 	})
 	return unsafe.Pointer(ctx), err
+}
+
+var (
+	modelMu     sync.Mutex
+	modelLoaded string // path of the ONNX file whose weights the shared context holds ("" = none)
+)
+
+// LoadModelOnce loads the ONNX file into the shared context unless that very file is already loaded: the reference calls
+// LoadPretrainedModelONNX once per request (workflow.go), and reloading would stall every embedder in flight behind the context's mutex.
+func LoadModelOnce(path string) error {
+	raw, e := Ctx()
+	if e != nil {
+		return e
+	}
+	modelMu.Lock()
+	defer modelMu.Unlock()
+	if modelLoaded == path {
+		return nil
+	}
+	p := C.CString(path)
+	defer C.free(unsafe.Pointer(p))
+	if rc := C.icl_model_load_onnx((*C.icl_ctx)(raw), p); rc != C.ICL_OK {
+		return fmt.Errorf("%s", C.GoString(C.icl_last_error((*C.icl_ctx)(raw))))
+	}
+	modelLoaded = path
+	return nil
 }
 
 // LastError returns the message of the last failed call on the context (stored in the context, not in TLS).
