@@ -26,6 +26,14 @@
 //     earlier -- dead by then, and never the storage of a cluster that is still tentative or alive (a batch holds at
 //     most WB_K tentative merges, so a truncated batch leaves every live row intact).  rowoff[creation id] is therefore
 //     written by the finish kernels when a cluster is picked.
+//
+// Distance BOUNDS (round 3; icl_set_ward_options, include/imageclust.h ICL_DIST_*): an entry with the SIGN BIT set is a proven lower
+// bound of the reference's value, not a value (distance_mfma.hip derives it).  From n = 4096 the initial matrix is filled with
+// such bounds by a GEMM on the matrix cores; the row scans (scan_row_min) evaluate an entry exactly -- the reference's own
+// sequential expression, ward_sqdist_wave -- only when its bound reaches the row's minimum, so nothing a comparison sees is
+// ever a bound.  On request (ICL_DIST_BOUND) the update kernel's main workgroups write the rows of the clusters being created
+// as bounds too (wx_main_bound: v_mfma_f32_16x16x4_f32), ward_newrow_min_kernel finds their exact minima from per-row
+// candidate lists and leaves each row a nearest-neighbour list; measured slower end to end than the exact rows.
 #pragma clang fp contract(off)
 
 #include "icl_common.h"
