@@ -208,6 +208,30 @@ def test_cluster_all_identical_points(ctx):
     same_as_oracle(ctx, np.ones((37, 5), np.float32), 2, 4)
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_adversarial_batches_with_distance_bounds(ctx, mode):
+    """The inputs aimed at the batched loop again, with distance bounds forced (auto mode only uses them from n = 4096): mode 3 =
+    bounds in the initial matrix, mode 2 = also in the rows of the clusters being created (candidate lists, exact minima from
+    the lists, nearest-neighbour lists; D = 4096 fills the update kernel's LDS to 158.7 KB).  Rolled-back batches, new clusters
+    that are each other's nearest neighbours (virtual-slot entries below every listed one), heavy ties (candidate lists overflow
+    into the full-scan path), targets reached inside a batch, identical points, NaN / Inf."""
+    ctx.set_ward_options(mode)
+    try:
+        test_batch_dependent_chain(ctx)
+        test_batch_new_clusters_merge_with_each_other(ctx)
+        for args in [(100, 4096, 2, 10), (90, 2052, 1, 7), (700, 6, 1, 9), (600, 5, 2, 40)]:
+            test_batch_paths_wide_and_odd_dims(ctx, *args)
+        test_batch_heavy_ties_at_scale(ctx)
+        test_batch_target_reached_inside_a_batch(ctx)
+        same_as_oracle(ctx, np.ones((37, 5), np.float32), 2, 4)
+        E = mog(40, 6, 3)
+        E[7, 2] = np.nan
+        E[11, 0] = np.inf
+        same_as_oracle(ctx, E, 1, 3)
+    finally:
+        ctx.set_ward_options(0)
+
+
 def test_cluster_nan_and_inf_rows(ctx):
     E = mog(40, 6, 3)
     E[7, 2] = np.nan
