@@ -538,27 +538,62 @@ __device__ __forceinline__ float ward_w2(int sa, int sb)
     const float num = (float)((int64_t)sa * (int64_t)sb), den = (float)(sa + sb);
     return 2.0f * (num / den);
 }
+// sum_k fl(fl(x_k - y_k)^2), strictly in k order, by ONE thread (d % 4 == 0): eight 16-byte loads of each row are in flight before
+// the first of them is used -- the loads depend on nothing, but issued one k-group at a time each waits for the round trip of the
+// previous one (a row pair took ~100 us that way)
+__device__ __forceinline__ float ward_sqdist_thread(const float *__restrict__ x, const float *__restrict__ y, int d)
+{
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const int ng = d >> 2;
+    float s = 0.0f;
+    int g = 0;
+    for (; g + 8 <= ng; g += 8) {
+        float4 xv[8], yv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            xv[q] = x4[g + q];
+            yv[q] = y4[g + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float df = xv[q].x - yv[q].x; // clustering.go:139
+            float p = df * df;            // :154 product (rounded)
+            s = s + p;                    // :154 sum (rounded), strictly in k order
+            df = xv[q].y - yv[q].y;
+            p = df * df;
+            s = s + p;
+            df = xv[q].z - yv[q].z;
+            p = df * df;
+            s = s + p;
+            df = xv[q].w - yv[q].w;
+            p = df * df;
+            s = s + p;
+        }
+    }
+    for (; g < ng; ++g) {
+        const float4 xv = x4[g], yv = y4[g];
+        float df = xv.x - yv.x;
+        float p = df * df;
+        s = s + p;
+        df = xv.y - yv.y;
+        p = df * df;
+        s = s + p;
+        df = xv.z - yv.z;
+        p = df * df;
+        s = s + p;
+        df = xv.w - yv.w;
+        p = df * df;
+        s = s + p;
+    }
+    return s;
+}
 // WardDistance of two SINGLETONS from their embeddings (clustering.go:136-157 with sizes 1, 1): sequential, unfused fp32
 __device__ __forceinline__ float ward_singleton_pair(const float *__restrict__ E, int d, int a, int b)
 {
     const float *x = E + (int64_t)a * d, *y = E + (int64_t)b * d;
     float s = 0.0f;
     if ((d & 3) == 0) {
-        for (int k = 0; k < d; k += 4) {
-            const float4 xv = *reinterpret_cast<const float4 *>(x + k), yv = *reinterpret_cast<const float4 *>(y + k);
-            float df = xv.x - yv.x; // clustering.go:139
-            float p = df * df;      // :154 product (rounded)
-            s = s + p;              // :154 sum (rounded), strictly in k order
-            df = xv.y - yv.y;
-            p = df * df;
-            s = s + p;
-            df = xv.z - yv.z;
-            p = df * df;
-            s = s + p;
-            df = xv.w - yv.w;
-            p = df * df;
-            s = s + p;
-        }
+        s = ward_sqdist_thread(x, y, d);
     } else {
         for (int k = 0; k < d; ++k) {
             const float df = x[k] - y[k];
@@ -576,21 +611,7 @@ __device__ __forceinline__ float ward_pair_value(const float *__restrict__ x, co
 {
     float s = 0.0f;
     if ((d & 3) == 0) {
-        for (int k = 0; k < d; k += 4) {
-            const float4 xv = *reinterpret_cast<const float4 *>(x + k), yv = *reinterpret_cast<const float4 *>(y + k);
-            float df = xv.x - yv.x;
-            float p = df * df;
-            s = s + p;
-            df = xv.y - yv.y;
-            p = df * df;
-            s = s + p;
-            df = xv.z - yv.z;
-            p = df * df;
-            s = s + p;
-            df = xv.w - yv.w;
-            p = df * df;
-            s = s + p;
-        }
+        s = ward_sqdist_thread(x, y, d);
     } else {
         for (int k = 0; k < d; ++k) {
             const float df = x[k] - y[k];
