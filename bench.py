@@ -141,8 +141,8 @@ def main():
                     help="N > 1, exact mode: who builds the initial distance matrix.  distributed: every rank computes an area-balanced run of "
                          "rows with the exact kernel and sends its span to rank 0 (point-to-point, 20 GB x (N-1)/N at 100 000 images); local: "
                          "rank 0 fills the whole matrix itself with the matrix-core bounds (0.19 s at 100 000 images, nothing to transport); "
-                         "auto: local up to 5 ranks (0.49 s / N of exact arithmetic + the transport only beat 0.19 s from about 6 ranks on), "
-                         "distributed beyond")
+                         "auto = local: 0.49 s / N of exact arithmetic + the transport only beat 0.19 s from about 6 ranks on (estimated "
+                         "0.12 s at 8), and the local build needs no point-to-point traffic at all")
     ap.add_argument("--ward-dist", choices=["auto", "exact", "bound", "bound-init"], default="auto",
                     help="exact mode only (include/imageclust.h ICL_DIST_*): how distances are produced -- every value on the vector ALUs, "
                          "or proven lower bounds from the matrix cores with exact evaluation on demand (same ids, bit for bit); "
@@ -225,7 +225,7 @@ def main():
             result["allgather_ms"] = (time.perf_counter() - t0) * 1e3
         if args.embed_only:
             return
-        if world > 1 and args.update == "exact" and (args.tiles == "distributed" or (args.tiles == "auto" and world >= 6)):
+        if world > 1 and args.update == "exact" and args.tiles == "distributed":
             # the initial distance matrix is built on ALL ranks (area-balanced runs of tile rows), every span goes to rank 0's
             # triangle over xGMI (point-to-point sends, no collective), rank 0 runs the exact merge loop
             t0 = time.perf_counter()
