@@ -7,7 +7,7 @@
 // types 0 (grey), 2 (RGB), 3 (palette), 4 (grey + alpha), 6 (RGBA) at bit depths 1-16.  What cv::imread(IMREAD_COLOR) makes of
 // them: 3 x 8-bit colour, alpha STRIPPED (not blended: png_set_strip_alpha), 16-bit samples cut to their high byte
 // (png_set_strip_16), grey 1 / 2 / 4 bits scaled to 0..255, palette looked up, tRNS / gAMA and every other ancillary chunk
-// ignored.  Adam7-interlaced files are rejected (ICL_ERR_UNSUPPORTED).
+// ignored.  Adam7-interlaced files are decoded pass by pass (PNG 8.2).
 //
 // Hostile input: every length comes from the file.  Chunk lengths are checked against the bytes that are there, CRCs and the
 // Adler-32 are verified, dimensions are capped like the JPEG reader's (64 Mpx), the inflated size must equal exactly
@@ -278,79 +278,102 @@ int icl_png_decode(icl_ctx *ctx, const uint8_t *data, size_t len, const char *pa
         pos += 12 + (size_t)clen;
     }
     if (!have_ihdr || !have_iend) return fail("truncated file (no IEND)");
-    if (interlace) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "failed to read image: %s. PNG: Adam7-interlaced files are not decoded by this build", path);
     if (ctype == 3 && npal == 0) return fail("palette image without PLTE");
     if (z.size() < 6) return fail("no image data");
     // zlib wrapper (RFC 1950): CM = 8, window <= 32 KiB, no preset dictionary, header check
     if ((z[0] & 0x0f) != 8 || (z[0] >> 4) > 7 || (z[1] & 0x20) || (((unsigned)z[0] << 8) | z[1]) % 31 != 0) return fail("bad zlib header");
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
-    const size_t bits_px = (size_t)channels * depth, rowb = ((size_t)w * bits_px + 7) / 8, bpp = bits_px >= 8 ? bits_px / 8 : 1;
-    const size_t want = (size_t)h * (rowb + 1);
+    const size_t bits_px = (size_t)channels * depth, bpp = bits_px >= 8 ? bits_px / 8 : 1;
+    // the reduced images of the stream (PNG 8.2): one for a progressive file, the seven Adam7 passes for an interlaced one -- each
+    // its own sequence of filtered scanlines; empty passes are absent from the stream
+    struct pass_t {
+        uint32_t xs, ys, dx, dy, pw, ph;
+        size_t rowb, off;
+    } passes[7];
+    int npass = 0;
+    size_t want = 0;
+    {
+        static const uint8_t a7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        const int np = interlace ? 7 : 1;
+        for (int q = 0; q < np; ++q) {
+            const uint32_t xs = interlace ? a7[q][0] : 0, ys = interlace ? a7[q][1] : 0, dx = interlace ? a7[q][2] : 1, dy = interlace ? a7[q][3] : 1;
+            if (xs >= w || ys >= h) continue;
+            const uint32_t pw = (w - xs + dx - 1) / dx, ph = (h - ys + dy - 1) / dy;
+            const size_t rowb = ((size_t)pw * bits_px + 7) / 8;
+            passes[npass++] = pass_t{xs, ys, dx, dy, pw, ph, rowb, want};
+            want += (size_t)ph * (rowb + 1);
+        }
+    }
     std::vector<uint8_t> raw;
     bits_in b{z.data() + 2, z.data() + z.size() - 4};
     if (!inflate_exact(b, raw, want)) return fail("corrupt or truncated DEFLATE stream");
     if (adler32_of(raw.data(), raw.size()) != be32(z.data() + z.size() - 4)) return fail("Adler-32 mismatch");
-    // scanline filters (PNG 9.2): Sub, Up, Average, Paeth over bytes, bpp bytes to the left
-    std::vector<uint8_t> zero(rowb, 0);
-    const uint8_t *prev = zero.data();
-    for (uint32_t y = 0; y < h; ++y) {
-        uint8_t *line = raw.data() + (size_t)y * (rowb + 1);
-        const uint8_t ft = line[0];
-        uint8_t *cur = line + 1;
-        switch (ft) {
-        case 0:
-            break;
-        case 1:
-            for (size_t i = bpp; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
-            break;
-        case 2:
-            for (size_t i = 0; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);
-            break;
-        case 3:
-            for (size_t i = 0; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + prev[i]) >> 1));
-            break;
-        case 4:
-            for (size_t i = 0; i < rowb; ++i) {
-                const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-                const int p = a + bb - c, pa = p > a ? p - a : a - p, pb = p > bb ? p - bb : bb - p, pc = p > c ? p - c : c - p;
-                cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
-            }
-            break;
-        default:
-            return fail("unknown scanline filter");
-        }
-        prev = cur;
-    }
     // -> 3 x 8-bit RGB as cv::imread(IMREAD_COLOR) delivers it (alpha stripped, 16 -> 8 by the high byte, small greys scaled)
     W = (int)w;
     H = (int)h;
     rgb.assign((size_t)w * h * 3, 0);
     const int step = depth == 16 ? 2 : 1; // bytes per sample for depth >= 8
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t *cur = raw.data() + (size_t)y * (rowb + 1) + 1;
-        uint8_t *o = rgb.data() + (size_t)y * w * 3;
-        for (uint32_t x = 0; x < w; ++x, o += 3) {
-            if (ctype == 2 || ctype == 6) {
-                const uint8_t *s = cur + (size_t)x * channels * step;
-                o[0] = s[0];
-                o[1] = s[step];
-                o[2] = s[2 * step];
-            } else if (ctype == 4 || (ctype == 0 && depth >= 8)) {
-                o[0] = o[1] = o[2] = cur[(size_t)x * channels * step];
-            } else { // packed samples: grey 1 / 2 / 4 bits or palette indices 1 / 2 / 4 / 8 bits
-                unsigned v;
-                if (depth == 8) v = cur[x];
-                else {
-                    const size_t bit = (size_t)x * depth;
-                    v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+    std::vector<uint8_t> zero(((size_t)w * bits_px + 7) / 8, 0);
+    for (int q = 0; q < npass; ++q) {
+        const pass_t &ps = passes[q];
+        const size_t rowb = ps.rowb;
+        // scanline filters (PNG 9.2): Sub, Up, Average, Paeth over bytes, bpp bytes to the left; the line above the first one of a pass is zero
+        const uint8_t *prev = zero.data();
+        for (uint32_t y = 0; y < ps.ph; ++y) {
+            uint8_t *line = raw.data() + ps.off + (size_t)y * (rowb + 1);
+            const uint8_t ft = line[0];
+            uint8_t *cur = line + 1;
+            switch (ft) {
+            case 0:
+                break;
+            case 1:
+                for (size_t i = bpp; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < rowb; ++i) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + prev[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < rowb; ++i) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                    const int p = a + bb - c, pa = p > a ? p - a : a - p, pb = p > bb ? p - bb : bb - p, pc = p > c ? p - c : c - p;
+                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
                 }
-                if (ctype == 3) {
-                    if ((int)v >= npal) return fail("palette index out of range");
-                    o[0] = pal[v][0];
-                    o[1] = pal[v][1];
-                    o[2] = pal[v][2];
-                } else {
-                    o[0] = o[1] = o[2] = (uint8_t)(v * (255u / ((1u << depth) - 1u)));
+                break;
+            default:
+                return fail("unknown scanline filter");
+            }
+            prev = cur;
+        }
+        for (uint32_t y = 0; y < ps.ph; ++y) {
+            const uint8_t *cur = raw.data() + ps.off + (size_t)y * (rowb + 1) + 1;
+            uint8_t *orow = rgb.data() + (size_t)(ps.ys + y * ps.dy) * w * 3;
+            for (uint32_t x = 0; x < ps.pw; ++x) {
+                uint8_t *o = orow + (size_t)(ps.xs + x * ps.dx) * 3;
+                if (ctype == 2 || ctype == 6) {
+                    const uint8_t *sp = cur + (size_t)x * channels * step;
+                    o[0] = sp[0];
+                    o[1] = sp[step];
+                    o[2] = sp[2 * step];
+                } else if (ctype == 4 || (ctype == 0 && depth >= 8)) {
+                    o[0] = o[1] = o[2] = cur[(size_t)x * channels * step];
+                } else { // packed samples: grey 1 / 2 / 4 bits or palette indices 1 / 2 / 4 / 8 bits
+                    unsigned v;
+                    if (depth == 8) v = cur[x];
+                    else {
+                        const size_t bit = (size_t)x * depth;
+                        v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                    }
+                    if (ctype == 3) {
+                        if ((int)v >= npal) return fail("palette index out of range");
+                        o[0] = pal[v][0];
+                        o[1] = pal[v][1];
+                        o[2] = pal[v][2];
+                    } else {
+                        o[0] = o[1] = o[2] = (uint8_t)(v * (255u / ((1u << depth) - 1u)));
+                    }
                 }
             }
         }

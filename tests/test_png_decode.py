@@ -136,7 +136,8 @@ def test_hostile_png_files_are_rejected_not_crashed(tmp_path):
         b[pos] ^= 0x5A
         bad(bytes(b), "flip%d.png" % pos)
     row = (0, bytes(30))
-    bad(raw_png(10, 1, 8, 2, [row], interlace=1), "adam7.png")                      # interlaced: unsupported, said so
+    bad(raw_png(10, 1, 8, 2, [row], interlace=1), "adam7.png")                      # interlaced, but the stream holds one progressive row: 31 bytes for 34
+    bad(raw_png(10, 1, 8, 2, [row], interlace=2), "interlace2.png")                 # unknown interlace method
     bad(raw_png(10, 1, 8, 2, [(7, bytes(30))]), "filter7.png")                      # unknown filter type
     bad(raw_png(10, 1, 8, 2, [(0, bytes(29))]), "short.png")                        # too few bytes inflated
     bad(raw_png(10, 1, 8, 2, [row, row]), "long.png")                               # too many
@@ -155,3 +156,76 @@ def test_hostile_png_files_are_rejected_not_crashed(tmp_path):
     # random garbage behind a valid signature never crashes
     for i in range(40):
         bad(b"\x89PNG\r\n\x1a\n" + rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes(), "rnd%d.png" % i)
+
+
+def adam7_png(samples, depth, ctype, extra=b"", filters=(0, 1, 2, 3, 4)):
+    """An Adam7-interlaced PNG built by hand from samples[h][w][channels] (ints below 2**depth): the seven reduced images, each
+    with its own filtered scanlines (the filter types cycle through `filters`); empty passes are left out, as the standard says."""
+    h, w, ch = samples.shape
+    bpp = max(1, ch * depth // 8)
+    raw = b""
+    k = 0
+    for xs, ys, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        sub = samples[ys::dy, xs::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for row in sub:
+            vals = row.reshape(-1)
+            if depth == 16:
+                cur = np.stack([vals >> 8, vals & 255], 1).reshape(-1).astype(np.int32)
+            elif depth == 8:
+                cur = vals.astype(np.int32)
+            else:
+                bits = "".join(format(int(v), "0%db" % depth) for v in vals)
+                bits += "0" * (-len(bits) % 8)
+                cur = np.array([int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)], np.int32)
+            if prev is None:
+                prev = np.zeros_like(cur)
+            left = np.r_[np.zeros(bpp, np.int32), cur[:-bpp]]
+            ul = np.r_[np.zeros(bpp, np.int32), prev[:-bpp]]
+            ft = filters[k % len(filters)]
+            k += 1
+            if ft == 0:
+                enc = cur
+            elif ft == 1:
+                enc = cur - left
+            elif ft == 2:
+                enc = cur - prev
+            elif ft == 3:
+                enc = cur - ((left + prev) >> 1)
+            else:
+                pa, pb, pc = np.abs(prev - ul), np.abs(left - ul), np.abs(left + prev - 2 * ul)
+                enc = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            raw += bytes([ft]) + bytes((enc & 255).astype(np.uint8))
+            prev = cur
+    z = zlib.compress(raw, 6)
+    idat = chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:])
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + extra + idat + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (8, 8), (9, 17), (37, 29), (130, 67)])
+def test_adam7_interlaced_files(tmp_path, size):
+    """cv::imread reads interlaced PNGs like any other: the seven passes are de-interleaved into the same image.  Hand-built files
+    (Pillow cannot write them) in every colour type; Pillow READS them, and must agree with this decoder and with the source."""
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    pal = rng.integers(0, 256, 48, dtype=np.uint8).tobytes()
+    cases = [("rgb8", 8, 2, 3, b""), ("rgba16", 16, 6, 4, b""), ("grey2", 2, 0, 1, b""), ("pal4", 4, 3, 1, chunk(b"PLTE", pal)), ("ga8", 8, 4, 2, b""),
+             ("grey16", 16, 0, 1, b""), ("grey1", 1, 0, 1, b"")]
+    for name, depth, ctype, ch, extra in cases:
+        s = rng.integers(0, 1 << depth, (h, w, ch), dtype=np.int64)
+        data = adam7_png(s, depth, ctype, extra)
+        got = decode(tmp_path, data, name + ".png")
+        if ctype == 3:
+            lut = np.frombuffer(pal, np.uint8).reshape(16, 3)
+            want = lut[s[:, :, 0]]
+        elif ctype in (0, 4):
+            g = s[:, :, 0]
+            g8 = (g >> 8) if depth == 16 else g * (255 // ((1 << depth) - 1))
+            want = np.repeat(g8[:, :, None], 3, 2).astype(np.uint8)
+        else:
+            want = ((s[:, :, :3] >> 8) if depth == 16 else s[:, :, :3]).astype(np.uint8)
+        assert got.shape == want.shape and np.array_equal(got, want), (name, size)
+        if depth <= 8 and ctype in (2, 3):  # and Pillow's reader on the same file (its 16-bit / grey conversions differ from cv::imread's by design)
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), want), (name, size)
