@@ -79,7 +79,7 @@ int icl_synthetic_blob(uint64_t seed, void *blob, int64_t bytes); /* host only, 
  * (a helper thread owned by the call) overlaps the forward passes of the current one.  The _dev variant takes device pointers. */
 int icl_embed_u8(icl_ctx *ctx, const uint8_t *hwc_rgb, int64_t n, int head, int prec, float *out);
 int icl_embed_u8_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int head, int prec, float *d_out);
-/* One image file (baseline or progressive Huffman JPEG, non-interlaced PNG, or binary PPM "P6"): decode, bilinear resize to 224x224
+/* One image file (baseline or progressive Huffman JPEG, PNG (progressive or Adam7-interlaced), or binary PPM "P6"): decode, bilinear resize to 224x224
  * (embeddings.go:69), then as icl_embed_u8 with n = 1, fp32. */
 int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
 /* icl_embed_file is what GetImageEmbedding(appCtx, path) binds to, and workflow.go:156-175 calls that from one goroutine per
@@ -88,7 +88,7 @@ int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
  * result bit for bit) or ICL_PREC_BF16.  window_us = 0 disables waiting (a lone caller runs at once). */
 int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch);
 int icl_file_batch_stats(icl_ctx *ctx, int64_t *batches, int64_t *images); /* forward passes run / images served by icl_embed_file */
-/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, non-interlaced PNG, or binary PPM) to interleaved RGB.
+/* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, PNG, or binary PPM) to interleaved RGB.
  * With rgb == NULL only *w / *h are returned.  cap_bytes must be >= w*h*3. */
 int icl_decode_image_file(const char *path, uint8_t *rgb, int64_t cap_bytes, int32_t *w, int32_t *h);
 /* decode + cv::resize(INTER_LINEAR)-compatible resize to 224x224 (embeddings.go:50,69): out is 224*224*3 u8 RGB. */
