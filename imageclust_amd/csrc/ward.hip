@@ -3340,6 +3340,23 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         if (bm) J = __ffsll((long long)bm) - 1;
         if (lane == 0) sh[0] = J;
     }
+    // wave 0's later dependent global loads, requested NOW (their addresses only need the snapshot): the columns of the picks' members
+    // (commit bookkeeping), the slots of the preselected next picks (express path; entries this kernel's commits move are overridden
+    // from the lane map, as before) and the row storage the next picks inherit after a full commit of WB_K merges
+    // (ward_new_row: q - WB_K is then this batch's own merge j, whose a is ls.B.a[j]).  ~1.5 us each when waited for in turn.
+    int pf_mca = 0, pf_mcb = 0, pf_gs = -1;
+    int64_t pf_ro = 0;
+    if (wave == 0) {
+        if (lane < nbp) {
+            const int a = ls.B.a[lane], b = ls.B.b[lane];
+            pf_mca = mcol[a];
+            pf_mcb = mcol[b];
+            pf_ro = rowoff[a];
+        }
+        const int pn_ = ls.B.pre_n;
+        const int pid = lane < pn_ ? ls.B.pre_row[lane < WB_K ? lane : 0] : (lane >= WB_K && lane < WB_K + pn_) ? ls.B.pre_nn[lane - WB_K] : -1;
+        if (pid >= 0) pf_gs = id_slot[pid];
+    }
     wb_map idm{-2, -1}, slm{-2, -1}; // id -> slot, slot -> id (wave 0 only)
     int rec = -1, frm = -1;          // wave 0: lane r = destination slot of write record r; lane j = source slot of move j
     const bool full0 = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0; // wave 0's view (its J is final)
@@ -3424,7 +3441,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             {
                 // recycled storage (file header): c takes over a's column, b's column dies.  The picks of a batch are pairwise
                 // disjoint, so the lanes touch different columns.
-                const int ca = mcol[a], cb = mcol[b];
+                const int ca = pf_mca, cb = pf_mcb; // (= mcol[a], mcol[b]: requested at the top)
                 mcol[c] = ca;
                 msz[ca] = ls.B.sa[j] + ls.B.sb[j];
                 mcid[ca] = c;
@@ -3485,7 +3502,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 int myid = -1;
                 if (lane < np) myid = ls.B.pre_row[lane];
                 else if (lane >= WB_K && lane < WB_K + np) myid = ls.B.pre_nn[lane - WB_K];
-                int gs = myid >= 0 ? id_slot[myid] : -1;
+                int gs = myid >= 0 ? pf_gs : -1; // (= id_slot[myid]: requested at the top; np <= pre_n, same lanes)
                 for (int m = 0; m < 4 * WB_K; ++m) { // entries touched by this kernel come from the lane map
                     const int mk = __builtin_amdgcn_readlane(idm.key, m), mv = __builtin_amdgcn_readlane(idm.val, m); // (wave-uniform lane index)
                     if (mk >= 0 && mk == myid) gs = mv;
@@ -3535,7 +3552,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.ub2[j] = 0x7f7fffffu; // MaxFloat32
                         st->B.cand_n[j] = 0;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
-                        rowoff[n + t1 + j] = ward_new_row(n, ld, t1 + j, t0, ls.B.a, merges, rowoff);
+                        rowoff[n + t1 + j] = (J == WB_K && t1 + j >= WB_K) ? pf_ro : ward_new_row(n, ld, t1 + j, t0, ls.B.a, merges, rowoff);
                     } else if (lane >= WB_K && lane < WB_K + np)
                         pk_slb[lane - WB_K] = srcsel;
                     if (lane == 0) {
