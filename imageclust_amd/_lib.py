@@ -55,6 +55,8 @@ SYMBOLS = [
     ("icl_load_image_224", _int, [C.c_char_p, _vp]),
     ("icl_set_batch", _int, [_vp, _int]),
     ("icl_conv2d_fused", _int, [_vp, _int, _vp, _int, _int, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _int, _vp]),
+    ("icl_stem_pool", _int, [_vp, _int, _vp, _int, _vp]),
+    ("icl_bottleneck56", _int, [_vp, _vp, _int, _int, _int, _int] + [_vp] * 13),
     ("icl_calc_optimal_clusters", _int, [_i64, _i64, _i64, _pi64]),
     ("icl_ward_distance_matrix", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
     ("icl_ward_distance_matrix_dev", _int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64]),
@@ -282,6 +284,25 @@ class Context:
         check(self.h, self.L.icl_conv2d_fused(self.h, prec, x.ctypes.data, B, H, Cin, w.ctypes.data, Cout, k, stride, pad,
                                               sc.ctypes.data, sh.ctypes.data, None if r is None else r.ctypes.data,
                                               1 if relu else 0, y.ctypes.data))
+        return y
+
+    def stem_pool(self, imgs, prec=PREC_FP32):
+        """conv0 + BN + ReLU + maxpool of the loaded model in one launch: [B][56][56][64] fp32."""
+        a = np.ascontiguousarray(imgs, np.uint8).reshape(-1, IMG_BYTES)
+        out = np.empty((a.shape[0], 56, 56, 64), np.float32)
+        check(self.h, self.L.icl_stem_pool(self.h, prec, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def bottleneck56(self, x_nhwc, w1, bn1, w2_oihw, bn2, w3, bn3, wds=None, bnds=None):
+        """One fused stage-1 bottleneck (bf16): bnK = (scale, shift).  wds / bnds select the downsample-branch form."""
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        x = f(x_nhwc)
+        B, H, W, Cin = x.shape
+        y = np.empty((B, H, W, 256), np.float32)
+        keep = [x, f(w1), f(bn1[0]), f(bn1[1]), f(w2_oihw), f(bn2[0]), f(bn2[1]), f(w3), f(bn3[0]), f(bn3[1])]
+        keep += [None, None, None] if wds is None else [f(wds), f(bnds[0]), f(bnds[1])]
+        ptr = [None if a is None else a.ctypes.data for a in keep]
+        check(self.h, self.L.icl_bottleneck56(self.h, ptr[0], B, H, W, Cin, *ptr[1:], y.ctypes.data))
         return y
 
     def synth_images_dev(self, seed, first, n, mode, d_out):

@@ -45,6 +45,8 @@ struct conv_args {
     int H2, W2, Cin2, stride2;
 };
 
+#include "resnet_fused.h"
+
 // Epilogue: y = relu(acc*scale + shift (+ residual)).
 // accumulators (lane = pixel, 4 consecutive channels per register quad) -> fp32 LDS tile [pixel][channel] -> one
 // 16-byte channel chunk per lane, so residual reads and output stores are whole contiguous rows; a lane's chunk column
@@ -504,10 +506,6 @@ static constexpr size_t conv_lds_bytes(int nstages = 2)
 // conv's zero padding), chunks are cut out of it with aligned ds_read_b32 + v_alignbyte, scaled by float(1/255) as
 // BlobFromImage does (embeddings.go:96), converted, and written into the swizzled LDS image the MFMA step reads.
 // ------------------------------------------------------------------------------------------------------------
-#define STEM_K 192
-#define STEM_ROWK 24         /* k slots per filter row (21 used) */
-#define STEM_PW 120          /* patch row stride in bytes: 3 (alignment) + 37 pixels * 3 = 114, + slack for the padded slots, 4-aligned */
-#define STEM_PH 21
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t *__restrict__ img, const conv_args p)
 {
@@ -721,6 +719,8 @@ struct conv_layer {
     // block-0 c3 only: [Cout][mid + cin] = [W3*scale3 | Wds*scale_ds] and shift3 + shift_ds (downsample fused in)
     void *wfused[2] = {nullptr, nullptr};
     float *shift_fused = nullptr;
+    // stage 1 only (bneck56_kernel): bf16(W * scale), the BatchNorm scale folded into the weights before rounding
+    void *wfold = nullptr;
 };
 
 struct icl_model {
@@ -843,7 +843,7 @@ void icl_model_free(icl_ctx *ctx)
     icl_model *m = ctx->model;
     if (!m) return;
     for (auto &c : m->conv) {
-        for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift, c.wfused[0], c.wfused[1], (void *)c.shift_fused})
+        for (void *p : {c.w[0], c.w[1], (void *)c.scale, (void *)c.shift, c.wfused[0], c.wfused[1], (void *)c.shift_fused, c.wfold})
             if (p) (void)hipFree(p);
     }
     for (void *p : {(void *)m->fcw, (void *)m->fcb, m->zero, (void *)m->ones})
@@ -928,6 +928,10 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
         }
         ICL_TRY(upload(ctx, (void **)&L.scale, sc.data(), (size_t)cout * 4));
         ICL_TRY(upload(ctx, (void **)&L.shift, sh.data(), (size_t)cout * 4));
+        if (t[i].stage == 1 && t[i].role >= 1 && t[i].role <= 3) { // the fused stage-1 bottleneck takes its BN scales inside the weights
+            for (size_t e = 0; e < wf.size(); ++e) wb[e] = host_bf16(wf[e] * sc[e / (size_t)L.K]);
+            ICL_TRY(upload(ctx, &L.wfold, wb.data(), wb.size() * 2));
+        }
         if (t[i].block == 0 && (t[i].role == 3 || t[i].role == 4)) {
             hw[(size_t)i] = wf;
             hsc[(size_t)i] = sc;
@@ -1212,6 +1216,65 @@ static int launch_conv_fused_ds(icl_ctx *ctx, int prec, const conv_layer &c3, co
     return prec == ICL_PREC_BF16 ? launch_conv_t<BF16>(ctx, a) : launch_conv_t<F32>(ctx, a);
 }
 
+// ICL_FUSE (A/B measurements and the fused == unfused tests): bit 0 stem + maxpool in one launch, bit 1 the identity
+// bottlenecks of stage 1 in one launch each, bit 2 stage 1's first bottleneck (downsample branch).  Default: all.
+static int fuse_mask()
+{
+    static const int m = [] {
+        const char *e = getenv("ICL_FUSE");
+        return e ? atoi(e) : 7;
+    }();
+    return m;
+}
+
+template <typename T>
+static void launch_stem_pool(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, void *pooled, hipStream_t strm)
+{
+    icl_model *m = ctx->model;
+    icl_lds_optin(ctx, (const void *)stem_pool_kernel<T>, (int)stem_pool_lds_bytes<T>());
+    conv_args a;
+    const conv_layer &L = m->conv[0];
+    a.X = nullptr; a.Wt = L.w[prec]; a.Y = pooled; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
+    a.B = B; a.H = a.W = 224; a.Cin = 3; a.Ho = a.Wo = 112; a.Cout = 64; a.KH = a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+    a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * SP_STRIPS * SP_TILES; a.gy = 1;
+    a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
+    icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
+    const int nunits = B * SP_STRIPS;
+    const int per_cu = std::max<int>(1, (int)((size_t)160 * 1024 / stem_pool_lds_bytes<T>()));
+    const unsigned grid = (unsigned)std::min<int64_t>(nunits, (int64_t)per_cu * ctx->prop.multiProcessorCount);
+    hipLaunchKernelGGL((stem_pool_kernel<T>), dim3(grid), dim3(256), stem_pool_lds_bytes<T>(), strm, d_img, a, nunits);
+}
+
+// One stage-1 bottleneck in one launch (bf16): c1 -> c2 -> c3 (+ residual x | + downsample branch ds) + ReLU.
+static int launch_bneck56(icl_ctx *ctx, const conv_layer &c1, const conv_layer &c2, const conv_layer &c3, const conv_layer *ds, const void *x, void *y,
+                          int B, hipStream_t strm)
+{
+    bneck_args a;
+    a.X = (const uint16_t *)x;
+    a.Y = (uint16_t *)y;
+    a.W1 = (const uint16_t *)c1.wfold;
+    a.W2 = (const uint16_t *)c2.wfold;
+    a.W3 = (const uint16_t *)(ds ? c3.wfused[ICL_PREC_BF16] : c3.wfold);
+    a.sh1 = c1.shift; a.sh2 = c2.shift;
+    a.sh3 = ds ? c3.shift_fused : c3.shift;
+    a.zero = ctx->model->zero;
+    a.B = B; a.H = c2.rec.hin; a.W = c2.rec.hin;
+    a.nstrips = (a.W + BN56_COLS - 1) / BN56_COLS;
+    a.ngroups = std::max(1, std::min(B, ctx->prop.multiProcessorCount / a.nstrips));
+    const double px = (double)B * a.H * a.W;
+    icl_prof_scope ps(ctx, ICL_K_CONV, 2.0 * px * (64.0 * c1.rec.cin + 64.0 * 576 + 256.0 * (ds ? 128 : 64)), 0.0);
+    const dim3 grid((unsigned)(a.nstrips * a.ngroups));
+    if (ds) {
+        icl_lds_optin(ctx, (const void *)bneck56_kernel<true>, (int)bneck56_lds_bytes<true>());
+        hipLaunchKernelGGL((bneck56_kernel<true>), grid, dim3(512), bneck56_lds_bytes<true>(), strm, a);
+    } else {
+        icl_lds_optin(ctx, (const void *)bneck56_kernel<false>, (int)bneck56_lds_bytes<false>());
+        hipLaunchKernelGGL((bneck56_kernel<false>), grid, dim3(512), bneck56_lds_bytes<false>(), strm, a);
+    }
+    ICL_HIP(ctx, hipGetLastError());
+    return ICL_OK;
+}
+
 template <typename T>
 static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, int head, float *d_out, int lane, hipStream_t strm)
 {
@@ -1221,27 +1284,37 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     const int grid = 256 * 8;
     elem *x = (elem *)m->buf[lane][0], *t1 = (elem *)m->buf[lane][1], *t2 = (elem *)m->buf[lane][2], *ds = (elem *)m->buf[lane][3],
          *y = (elem *)m->buf[lane][4];
-    {
-        icl_lds_optin(ctx, (const void *)stem_conv_kernel<T>, (int)stem_lds_bytes<T>());
-        conv_args a;
-        const conv_layer &L = m->conv[0];
-        a.X = nullptr; a.Wt = L.w[prec]; a.Y = y; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
-        a.B = B; a.H = a.W = 224; a.Cin = 3; a.Ho = a.Wo = 112; a.Cout = 64; a.KH = a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
-        a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
-        a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
-        icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
-        const int per_cu = std::max<int>(1, (int)((size_t)160 * 1024 / stem_lds_bytes<T>()));
-        const unsigned stem_grid = (unsigned)std::min<int64_t>(a.gx, (int64_t)per_cu * ctx->prop.multiProcessorCount);
-        hipLaunchKernelGGL((stem_conv_kernel<T>), dim3(stem_grid), dim3(256), stem_lds_bytes<T>(), strm, d_img, a);
-    }
-    {
-        icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
-        hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, strm, y, B, 112, 64, x);
+    if (fuse_mask() & 1) {
+        launch_stem_pool<T>(ctx, prec, d_img, B, x, strm); // conv0 + BN + ReLU + maxpool: the 112x112 tensor stays on the CU
+    } else {
+        {
+            icl_lds_optin(ctx, (const void *)stem_conv_kernel<T>, (int)stem_lds_bytes<T>());
+            conv_args a;
+            const conv_layer &L = m->conv[0];
+            a.X = nullptr; a.Wt = L.w[prec]; a.Y = y; a.R = nullptr; a.scale = L.scale; a.shift = L.shift; a.zero = m->zero;
+            a.B = B; a.H = a.W = 224; a.Cin = 3; a.Ho = a.Wo = 112; a.Cout = 64; a.KH = a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+            a.M = (int64_t)B * 112 * 112; a.K = STEM_K; a.gx = B * 98; a.gy = 1; // 8x16-pixel tiles: 14 x 7 per image
+            a.X2 = nullptr; a.H2 = a.W2 = a.Cin2 = a.stride2 = 0;
+            icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)a.M * 64 * 147, 0.0);
+            const int per_cu = std::max<int>(1, (int)((size_t)160 * 1024 / stem_lds_bytes<T>()));
+            const unsigned stem_grid = (unsigned)std::min<int64_t>(a.gx, (int64_t)per_cu * ctx->prop.multiProcessorCount);
+            hipLaunchKernelGGL((stem_conv_kernel<T>), dim3(stem_grid), dim3(256), stem_lds_bytes<T>(), strm, d_img, a);
+        }
+        {
+            icl_prof_scope ps(ctx, ICL_K_EMBED_OTHER, 0.0, (double)B * (802816.0 + 200704.0) * sizeof(elem));
+            hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, strm, y, B, 112, 64, x);
+        }
     }
     int ci = 1;
     while (ci < m->nconv) {
         const conv_layer &c1 = m->conv[ci], &c2 = m->conv[ci + 1], &c3 = m->conv[ci + 2];
         const bool has_ds = c1.rec.block == 0;
+        if (prec == ICL_PREC_BF16 && c1.rec.stage == 1 && (fuse_mask() & (has_ds ? 4 : 2))) { // the whole bottleneck in one launch
+            ICL_TRY(launch_bneck56(ctx, c1, c2, c3, has_ds ? &m->conv[ci + 3] : nullptr, x, y, B, strm));
+            std::swap(x, y);
+            ci += has_ds ? 4 : 3;
+            continue;
+        }
         ICL_TRY(launch_conv(ctx, prec, c1, x, t1, nullptr, 1, B));
         ICL_TRY(launch_conv(ctx, prec, c2, t1, t2, nullptr, 1, B));
         if (has_ds)
@@ -1264,6 +1337,120 @@ static int forward_batch(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, in
     }
     ICL_HIP(ctx, hipGetLastError());
     return ICL_OK;
+}
+
+// The fused stem of the loaded model alone (conv0 7x7/2 + BN + ReLU + maxpool 3x3/2, stem_pool_kernel): img is B x 224x224x3
+// u8 HWC RGB (host), out is [B][56][56][64] NHWC fp32 (host).  For the per-layer parity tests.
+extern "C" int icl_stem_pool(icl_ctx *ctx, int prec, const uint8_t *img, int B, float *out)
+{
+    if (!ctx || !img || !out || B < 1) return icl_fail(ctx, ICL_ERR_ARG, "icl_stem_pool: bad argument");
+    if (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) return icl_fail(ctx, ICL_ERR_ARG, "bad prec");
+    return no_throw(ctx, "icl_stem_pool", [&]() -> int {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        icl_device_guard g(ctx->device);
+        if (!ctx->model) return icl_fail(ctx, ICL_ERR_NOMODEL, "no model loaded (call icl_model_load_* first)");
+        const size_t es = prec == ICL_PREC_BF16 ? 2 : 4, ny = (size_t)B * 56 * 56 * 64;
+        uint8_t *dimg = nullptr;
+        void *dy = nullptr;
+        int rc = ICL_OK;
+        if (hipMalloc((void **)&dimg, (size_t)B * ICL_IMG_BYTES) != hipSuccess || hipMalloc(&dy, ny * es) != hipSuccess)
+            rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_stem_pool: device buffers");
+        if (!rc && hipMemcpy(dimg, img, (size_t)B * ICL_IMG_BYTES, hipMemcpyHostToDevice) != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_stem_pool: upload");
+        if (!rc) {
+            if (prec == ICL_PREC_BF16) launch_stem_pool<BF16>(ctx, prec, dimg, B, dy, ctx->stream);
+            else launch_stem_pool<F32>(ctx, prec, dimg, B, dy, ctx->stream);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) {
+                if (prec == ICL_PREC_BF16) {
+                    std::vector<uint16_t> t(ny);
+                    e = hipMemcpy(t.data(), dy, ny * 2, hipMemcpyDeviceToHost);
+                    for (size_t i = 0; i < ny; ++i) out[i] = host_from_bf16(t[i]);
+                } else {
+                    e = hipMemcpy(out, dy, ny * 4, hipMemcpyDeviceToHost);
+                }
+            }
+            if (e != hipSuccess) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_stem_pool: %s", hipGetErrorString(e));
+        }
+        if (dimg) (void)hipFree(dimg);
+        if (dy) (void)hipFree(dy);
+        icl_prof_collect(ctx);
+        return rc;
+    });
+}
+
+// One fused stage-1 bottleneck (bneck56_kernel, bf16 operands), host buffers, for the per-layer parity tests:
+//   identity (wds == NULL, Cin = 256): y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x))))))) + x)
+//   downsample (wds != NULL, Cin = 64): y = relu(bn3(conv3(t2)) + bn_ds(conv_ds(x)))  (both BN scales folded into the weights)
+// x: [B][H][W][Cin] NHWC, w1: [64][Cin], w2: [64][64][3][3] (OIHW), w3: [256][64], wds: [256][Cin]; y: [B][H][W][256].
+extern "C" int icl_bottleneck56(icl_ctx *ctx, const float *x, int B, int H, int W, int Cin, const float *w1, const float *sc1, const float *sh1,
+                                const float *w2, const float *sc2, const float *sh2, const float *w3, const float *sc3, const float *sh3,
+                                const float *wds, const float *scds, const float *shds, float *y)
+{
+    if (!ctx || !x || !w1 || !sc1 || !sh1 || !w2 || !sc2 || !sh2 || !w3 || !sc3 || !sh3 || !y || B < 1 || H < 1 || W < 1)
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_bottleneck56: bad argument");
+    const bool has_ds = wds != nullptr;
+    if (has_ds && (!scds || !shds)) return icl_fail(ctx, ICL_ERR_ARG, "icl_bottleneck56: downsample scale / shift missing");
+    if (Cin != (has_ds ? 64 : 256)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_bottleneck56: Cin must be 256 (identity) or 64 (downsample branch)");
+    if ((int64_t)B * (H + 1) >= (1LL << 28)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_bottleneck56: too many rows");
+    return no_throw(ctx, "icl_bottleneck56", [&]() -> int {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        icl_device_guard g(ctx->device);
+        const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * 256;
+        const int K3 = has_ds ? 128 : 64;
+        std::vector<uint16_t> hx(nx), hw1((size_t)64 * Cin), hw2((size_t)64 * 576), hw3((size_t)256 * K3);
+        for (size_t i = 0; i < nx; ++i) hx[i] = host_bf16(x[i]);
+        // every BatchNorm scale goes into the weights before they are rounded, as icl_model_load_blob does for stage 1
+        for (size_t i = 0; i < hw1.size(); ++i) hw1[i] = host_bf16(w1[i] * sc1[i / (size_t)Cin]);
+        for (int co = 0; co < 64; ++co)
+            for (int c = 0; c < 64; ++c)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) hw2[(size_t)co * 576 + ((size_t)a * 3 + b) * 64 + c] = host_bf16(w2[(((size_t)co * 64 + c) * 3 + a) * 3 + b] * sc2[co]);
+        std::vector<float> h3(256);
+        for (int co = 0; co < 256; ++co) {
+            for (int c = 0; c < 64; ++c) hw3[(size_t)co * K3 + c] = host_bf16(w3[(size_t)co * 64 + c] * sc3[co]);
+            if (has_ds)
+                for (int c = 0; c < 64; ++c) hw3[(size_t)co * 128 + 64 + c] = host_bf16(wds[(size_t)co * 64 + c] * scds[co]);
+            h3[co] = has_ds ? sh3[co] + shds[co] : sh3[co];
+        }
+        void *dx = nullptr, *dy = nullptr, *dw1 = nullptr, *dw2 = nullptr, *dw3 = nullptr, *dz = nullptr;
+        float *d1h = nullptr, *d2h = nullptr, *d3h = nullptr;
+        int rc = upload(ctx, &dx, hx.data(), nx * 2);
+        if (!rc) rc = upload(ctx, &dw1, hw1.data(), hw1.size() * 2);
+        if (!rc) rc = upload(ctx, &dw2, hw2.data(), hw2.size() * 2);
+        if (!rc) rc = upload(ctx, &dw3, hw3.data(), hw3.size() * 2);
+        if (!rc) rc = upload(ctx, (void **)&d1h, sh1, 64 * 4);
+        if (!rc) rc = upload(ctx, (void **)&d2h, sh2, 64 * 4);
+        if (!rc) rc = upload(ctx, (void **)&d3h, h3.data(), 256 * 4);
+        if (!rc && (hipMalloc(&dz, 256) != hipSuccess || hipMemset(dz, 0, 256) != hipSuccess)) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_bottleneck56: zero page");
+        if (!rc && hipMalloc(&dy, ny * 2) != hipSuccess) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_bottleneck56: output alloc");
+        if (!rc) {
+            bneck_args a;
+            a.X = (const uint16_t *)dx; a.Y = (uint16_t *)dy; a.W1 = (const uint16_t *)dw1; a.W2 = (const uint16_t *)dw2; a.W3 = (const uint16_t *)dw3;
+            a.sh1 = d1h; a.sh2 = d2h; a.sh3 = d3h; a.zero = dz;
+            a.B = B; a.H = H; a.W = W;
+            a.nstrips = (W + BN56_COLS - 1) / BN56_COLS;
+            a.ngroups = std::max(1, std::min(B, ctx->prop.multiProcessorCount / a.nstrips));
+            const dim3 grid((unsigned)(a.nstrips * a.ngroups));
+            if (has_ds) {
+                icl_lds_optin(ctx, (const void *)bneck56_kernel<true>, (int)bneck56_lds_bytes<true>());
+                hipLaunchKernelGGL((bneck56_kernel<true>), grid, dim3(512), bneck56_lds_bytes<true>(), ctx->stream, a);
+            } else {
+                icl_lds_optin(ctx, (const void *)bneck56_kernel<false>, (int)bneck56_lds_bytes<false>());
+                hipLaunchKernelGGL((bneck56_kernel<false>), grid, dim3(512), bneck56_lds_bytes<false>(), ctx->stream, a);
+            }
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            std::vector<uint16_t> t(ny);
+            if (e == hipSuccess) e = hipMemcpy(t.data(), dy, ny * 2, hipMemcpyDeviceToHost);
+            if (e == hipSuccess)
+                for (size_t i = 0; i < ny; ++i) y[i] = host_from_bf16(t[i]);
+            else rc = icl_fail(ctx, ICL_ERR_HIP, "icl_bottleneck56: %s", hipGetErrorString(e));
+        }
+        for (void *q : {dx, dy, dw1, dw2, dw3, dz, (void *)d1h, (void *)d2h, (void *)d3h})
+            if (q) (void)hipFree(q);
+        return rc;
+    });
 }
 
 int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head, int prec, float *d_out); // also called by icl_embed_cluster_dev (ward.hip)

@@ -109,6 +109,19 @@ int icl_conv2d_fused(icl_ctx *ctx, int prec, const float *x, int B, int H, int C
                      int stride, int pad, const float *scale, const float *shift, const float *residual, int relu,
                      float *y);
 
+/* The two cross-layer fusions of the forward pass (the reference's OpenCV-DNN fuses layers inside Net.Forward,
+ * embeddings.go:141), exposed one at a time for the per-layer parity tests, host buffers:
+ * icl_stem_pool: conv0 7x7/2 + BN + ReLU + maxpool 3x3/2 of the LOADED model in one launch.  img: B x 224x224x3 u8 HWC RGB,
+ * out: [B][56][56][64] NHWC fp32.
+ * icl_bottleneck56: one whole stage-1 bottleneck in one launch (bf16 operands, fp32 accumulate; t1 / t2 rounded to bf16 as the
+ * layer-by-layer bf16 path stores them).  wds == NULL (Cin = 256): y = relu(bn3(conv3(relu(bn2(conv2_3x3(relu(bn1(conv1(x)))))))) + x);
+ * wds != NULL (Cin = 64): y = relu(bn3(conv3(t2)) + bn_ds(conv_ds(x))).  x: [B][H][W][Cin] NHWC, w1: [64][Cin], w2: [64][64][3][3]
+ * (OIHW), w3: [256][64], wds: [256][Cin], sc / sh: folded BatchNorm scale / shift per output channel, y: [B][H][W][256]. */
+int icl_stem_pool(icl_ctx *ctx, int prec, const uint8_t *hwc_rgb, int B, float *out);
+int icl_bottleneck56(icl_ctx *ctx, const float *x, int B, int H, int W, int Cin, const float *w1, const float *sc1, const float *sh1,
+                     const float *w2, const float *sc2, const float *sh2, const float *w3, const float *sc3, const float *sh3,
+                     const float *wds, const float *scds, const float *shds, float *y);
+
 /* ---- several GPUs behind one handle ------------------------------------------------------------------
  * workflow.go:89,161 run in ONE process: a group drives ndev contexts from ndev host threads.  embed shards the images by
  * contiguous index ranges; cluster computes the initial distance rows (clustering.go:61-73) on every GPU in area-balanced
