@@ -388,7 +388,9 @@ def main():
                                        else "configs[4] (250 GB distance matrix on GPU0)" if n_total == 250000
                                        else "configs[1]" if n_total == 10000 and world == 1 else "custom size",
                                        n_total, n_local, args.batch,
-                                       "" if args.embed_only else (" -> RCCL all-gather -> distance rows on all ranks, spans sent to GPU0" if world > 1 else "")))
+                                       "" if args.embed_only else ((" -> RCCL all-gather of E -> exact distance rows on all ranks, sent to rank 0 piecewise (point-to-point) and laid into its matrix"
+                                                                     if args.update == "exact" and args.tiles == "distributed"
+                                                                     else " -> RCCL all-gather of E -> rank 0 builds the whole distance matrix itself (matrix-core bounds)") if world > 1 else "")))
                                    + ("" if args.embed_only else " -> Ward min=%d max=%d (merge loop on GPU0) -> cluster ids on host" % (args.min_size, args.max_size)),
                        "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
                        "ward_update": "none (embed only)" if args.embed_only else "exact (ids bit-identical to the reference)" if args.update == "exact"

@@ -17,6 +17,7 @@ HEAD_POOLED, HEAD_DENSE0 = 2048, 1000
 PREC_FP32, PREC_BF16 = 0, 1
 UPDATE_EXACT, UPDATE_LW = 0, 1
 SYNTH_NOISE, SYNTH_STRUCTURED = 0, 1
+TILES_AUTO, TILES_LOCAL, TILES_DISTRIBUTED = 0, 1, 2
 K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER, K_CONV64 = range(7)
 K_NAMES = ["conv_igemm_kernel<*,128>", "ward_dist_exact_kernel", "dist_mfma_kernel", "row_argmin_*_kernel",
            "ward_update_exact_kernel", "embed_other", "conv_igemm_kernel<*,64>"]
@@ -81,8 +82,8 @@ SYMBOLS = [
     ("icl_ward_span", _int, [_i64, _i64, _pi64, _pi64]),
     ("icl_ward_distance_rows_dev", _int, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     ("icl_ward_prepare", _int, [_vp, _i64, _i32]),
-    ("icl_ward_span_ptr", _int, [_vp, _i64, _i64, C.POINTER(_vp), _pi64]),
-    ("icl_ward_deposit_dev", _int, [_vp, _i64, _i64, _vp]),
+    ("icl_ward_unpack_spans_dev", _int, [_vp, _i32, _pi64, _pi64, C.POINTER(_vp)]),
+    ("icl_group_set_options", _int, [_vp, _int]),
     ("icl_cluster_prefilled_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _i64, _i64, _vp, _vp, _pi32]),
     ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_cluster_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
@@ -373,17 +374,16 @@ class Context:
     def ward_prepare(self, n, d):
         check(self.h, self.L.icl_ward_prepare(self.h, n, d))
 
-    def ward_span_ptr(self, row_lo, row_hi):
-        """(device pointer, floats) of rows [row_lo, row_hi) inside this context's packed distance triangle."""
-        p, c = _vp(), _i64()
-        check(self.h, self.L.icl_ward_span_ptr(self.h, row_lo, row_hi, C.byref(p), C.byref(c)))
-        return p.value, c.value
-
     def ward_distance_rows_dev(self, d_E, n, d, row_lo, row_hi, d_span):
         check(self.h, self.L.icl_ward_distance_rows_dev(self.h, _vp(d_E), n, d, row_lo, row_hi, _vp(d_span)))
 
-    def ward_deposit_dev(self, row_lo, row_hi, d_span):
-        check(self.h, self.L.icl_ward_deposit_dev(self.h, row_lo, row_hi, _vp(d_span)))
+    def ward_unpack_spans_dev(self, spans):
+        """spans: [(row_lo, row_hi, device pointer readable from this GPU)]: packed rows -> the rows of the distance matrix."""
+        k = len(spans)
+        lo = (C.c_int64 * k)(*[int(t[0]) for t in spans])
+        hi = (C.c_int64 * k)(*[int(t[1]) for t in spans])
+        pp = (C.c_void_p * k)(*[int(t[2]) for t in spans])
+        check(self.h, self.L.icl_ward_unpack_spans_dev(self.h, k, lo, hi, pp))
 
     def cluster_prefilled_dev(self, d_E, n, d, min_size, max_size, own_lo, own_hi, update=UPDATE_EXACT):
         cid = np.full(max(n, 1), -1, np.int32)
@@ -459,6 +459,10 @@ class Group:
         if self.g:
             self.L.icl_group_destroy(self.g)
             self.g = _vp()
+
+    def set_options(self, tiles_mode=0):
+        """Who builds the initial distance matrix: TILES_AUTO (GPU 0 alone below 6 GPUs), TILES_LOCAL, TILES_DISTRIBUTED."""
+        self._check(self.L.icl_group_set_options(self.g, tiles_mode))
 
     def size(self):
         return self.L.icl_group_size(self.g)

@@ -3,11 +3,13 @@
 // (workflow.go:161,89) and cannot start one process per GPU, so the group drives N contexts from N host threads:
 //   * embed: images shard by contiguous index ranges (no exchange: every GPU holds the weights);
 //   * cluster: every GPU holds E (uploaded once to GPU 0 and passed on by peer copies, or -- icl_group_embed_cluster --
-//     assembled on the GPUs from the embedding shards without touching the host), computes the distance rows of an
-//     area-balanced run of 128-row tile rows (icl_ward_rows_partition) and its span is copied device-to-device into staging
-//     memory of GPU 0 (hipMemcpyPeerAsync: xGMI when the devices are peers); GPU 0 lays the spans out into its distance matrix
-//     and runs the exact merge loop.  Results are bit-identical to one GPU: the same kernel computes every row, only where it
-//     runs changes.
+//     assembled on the GPUs from the embedding shards without touching the host).  Below 6 GPUs GPU 0 fills the whole initial
+//     distance matrix itself from matrix-core bounds (faster than waiting for exact rows over one xGMI link per peer); from 6 GPUs
+//     on GPU 0 computes the first area-balanced run of 128-row tile rows (icl_ward_rows_partition) and every other GPU the exact
+//     values of its run into a buffer of its OWN memory, which GPU 0 reads over xGMI straight into its matrix rows
+//     (icl_ward_unpack_spans_dev on peer-mapped memory; bounded copies where the devices are no peers).  GPU 0 holds the 4 n^2-byte
+//     matrix and O(n d) beside it for any number of parts.  Results are bit-identical to one GPU: values decide every
+//     comparison, wherever they were computed.
 // Entries of `devices` may repeat (a test on a 1-GPU box builds a group of two contexts on device 0: the same code path,
 // the peer copy degenerates to a device-to-device copy).
 // The process-per-GPU path of bench.py uses the same building blocks (icl_ward_distance_rows_dev / icl_ward_span_ptr /
@@ -19,9 +21,12 @@
 
 struct icl_group {
     std::vector<icl_ctx *> ctx;
+    std::vector<char> peer0; // GPU 0 can read context i's device memory directly (same device, or peer access enabled)
+    int tiles_mode = ICL_TILES_AUTO;
     std::string err;
     std::mutex mu;
 };
+#define ICL_GROUP_DIST_MIN 6 /* GPUs from which the distance rows are dealt out by default (0.19 s local vs 0.49 s / N + transfer) */
 
 #define ICL_GROUP_MAX 64 /* contexts of a group (icl_group_create checks) */
 static int group_fail(icl_group *g, int code, const std::string &msg)
@@ -71,14 +76,27 @@ extern "C" int icl_group_create(const int32_t *devices, int32_t ndev, icl_group 
         }
     }
     // peer access between distinct devices (xGMI inside a node); failure is not fatal: copies then stage through the host
+    try {
+        g->peer0.assign((size_t)ndev, 0);
+    } catch (...) {
+        for (icl_ctx *p : g->ctx) icl_destroy(p);
+        delete g;
+        return icl_fail(nullptr, ICL_ERR_NOMEM, "icl_group_create: out of memory");
+    }
     for (int i = 0; i < ndev; ++i)
-        for (int j = 0; j < ndev; ++j)
-            if (devices[i] != devices[j]) {
+        for (int j = 0; j < ndev; ++j) {
+            bool ok = devices[i] == devices[j];
+            if (!ok) {
                 icl_device_guard dg(devices[i]);
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                    ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                }
                 (void)hipGetLastError(); // "already enabled" is fine
             }
+            if (i == 0) g->peer0[(size_t)j] = ok ? 1 : 0;
+        }
     *out = g;
     return ICL_OK;
 }
@@ -90,6 +108,13 @@ extern "C" void icl_group_destroy(icl_group *g)
     delete g;
 }
 
+extern "C" int icl_group_set_options(icl_group *g, int tiles_mode)
+{
+    if (!g || tiles_mode < ICL_TILES_AUTO || tiles_mode > ICL_TILES_DISTRIBUTED) return group_fail(g, ICL_ERR_ARG, "icl_group_set_options: bad argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->tiles_mode = tiles_mode;
+    return ICL_OK;
+}
 extern "C" int32_t icl_group_size(icl_group *g) { return g ? (int32_t)g->ctx.size() : 0; }
 extern "C" icl_ctx *icl_group_ctx(icl_group *g, int32_t i) { return (g && i >= 0 && i < (int32_t)g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
 extern "C" const char *icl_group_last_error(icl_group *g) { return g ? g->err.c_str() : ""; }
@@ -159,48 +184,91 @@ extern "C" int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t 
     });
 }
 
-// The distance build + merge loop of a group on embeddings that are ALREADY resident on every GPU (dE[i]: n x d on GPU i):
-// every GPU computes the distance rows of its area-balanced run of 128-row tile rows (GPU 0 too, at the same time); the spans
-// of GPUs 1.. are copied device-to-device into staging buffers of GPU 0 that were reserved up front, each by its own host
-// thread on a stream of its own -- no lock of GPU 0's context is taken on the way, so the N-1 spans arrive concurrently (one
-// xGMI link each) while GPU 0 computes; GPU 0 then lays the spans out into its matrix and runs the exact merge loop.
+// The distance build + merge loop of a group on embeddings that are ALREADY resident on every GPU (dE[i]: n x d on GPU i).
+// Local build: GPU 0 alone, matrix-core bounds (icl_cluster_dev).  Distributed build: GPUs 1.. compute the exact rows of their
+// area-balanced runs into buffers of their own memory; GPU 0 then reads those spans over xGMI straight into its matrix rows
+// (all peers concurrently, one link each) -- or, for a device that is no peer, through a bounded landing buffer --, computes
+// its own run from bounds and runs the exact merge loop.  Nothing is staged on GPU 0.
+static bool group_deals_rows(icl_group *g)
+{
+    const int parts = (int)g->ctx.size();
+    return parts > 1 && (g->tiles_mode == ICL_TILES_DISTRIBUTED || (g->tiles_mode == ICL_TILES_AUTO && parts >= ICL_GROUP_DIST_MIN));
+}
 static int group_cluster_resident(icl_group *g, const std::vector<float *> &dE, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                   int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
     const int parts = (int)g->ctx.size();
     icl_ctx *c0 = g->ctx[0];
+    if (!group_deals_rows(g)) {
+        const int rc = icl_cluster_dev(c0, dE[0], n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
+        return rc == ICL_OK ? rc : group_fail(g, rc, icl_last_error(c0));
+    }
     int rc = icl_ward_prepare(c0, n, d);
     if (rc != ICL_OK) return group_fail(g, rc, icl_last_error(c0));
-    std::vector<float *> dSpan((size_t)parts, nullptr), stage((size_t)parts, nullptr);
+    std::vector<float *> dSpan((size_t)parts, nullptr);
     std::vector<int64_t> lo((size_t)parts, 0), hi((size_t)parts, 0), cnt((size_t)parts, 0);
     for (int i = 0; i < parts && rc == ICL_OK; ++i) {
+        int64_t off = 0;
         rc = icl_ward_rows_partition(n, parts, i, &lo[(size_t)i], &hi[(size_t)i]);
-        void *p = nullptr;
-        if (rc == ICL_OK && hi[(size_t)i] > lo[(size_t)i]) rc = icl_ward_span_ptr(c0, lo[(size_t)i], hi[(size_t)i], &p, &cnt[(size_t)i]); // reserves the staging buffer on GPU 0
-        stage[(size_t)i] = (float *)p;
+        if (rc == ICL_OK) rc = icl_ward_span(lo[(size_t)i], hi[(size_t)i], &off, &cnt[(size_t)i]);
     }
-    if (rc != ICL_OK) return group_fail(g, rc, icl_last_error(c0));
+    if (rc != ICL_OK) return group_fail(g, rc, "row partition failed");
     rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
-        if (hi[(size_t)i] == lo[(size_t)i]) return ICL_OK;
-        if (i == 0) return icl_ward_distance_rows_dev(c, dE[0], n, d, lo[0], hi[0], stage[0]);
+        if (i == 0 || hi[(size_t)i] == lo[(size_t)i]) return ICL_OK; // GPU 0's own run is computed by the cluster call below
         void *p = nullptr;
         ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(cnt[(size_t)i] * 4, 16), &p));
         dSpan[(size_t)i] = (float *)p;
-        ICL_TRY(icl_ward_distance_rows_dev(c, dE[(size_t)i], n, d, lo[(size_t)i], hi[(size_t)i], dSpan[(size_t)i]));
-        icl_device_guard dg(c->device);
-        hipStream_t cs = nullptr;
-        hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMemcpyPeerAsync(stage[(size_t)i], c0->device, dSpan[(size_t)i], c->device, (size_t)cnt[(size_t)i] * 4, cs);
-        if (e == hipSuccess) e = hipStreamSynchronize(cs);
-        if (cs) (void)hipStreamDestroy(cs);
-        return e == hipSuccess ? (int)ICL_OK : icl_fail(c, ICL_ERR_HIP, "span of rows [%lld, %lld) -> GPU %d failed: %s", (long long)lo[(size_t)i], (long long)hi[(size_t)i], c0->device, hipGetErrorString(e));
+        return icl_ward_distance_rows_dev(c, dE[(size_t)i], n, d, lo[(size_t)i], hi[(size_t)i], dSpan[(size_t)i]);
     });
-    if (rc == ICL_OK) {
-        rc = icl_cluster_prefilled_dev(c0, dE[0], n, d, min_size, max_size, update, 0, 0, cluster_id, member_rank, n_clusters);
+    if (rc == ICL_OK) { // the spans GPU 0 can read where they lie: all at once
+        int64_t plo[ICL_GROUP_MAX], phi[ICL_GROUP_MAX];
+        const float *pp[ICL_GROUP_MAX];
+        int np = 0;
+        for (int i = 1; i < parts; ++i)
+            if (dSpan[(size_t)i] && g->peer0[(size_t)i]) {
+                plo[np] = lo[(size_t)i];
+                phi[np] = hi[(size_t)i];
+                pp[np++] = dSpan[(size_t)i];
+            }
+        if (np) rc = icl_ward_unpack_spans_dev(c0, np, plo, phi, pp);
+        if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
+    }
+    if (rc == ICL_OK) { // no peer access to a device: runs of whole rows through one landing buffer of at most 256 MiB (+ one row)
+        void *land = nullptr;
+        int64_t land_floats = 0;
+        for (int i = 1; i < parts && rc == ICL_OK; ++i) {
+            if (!dSpan[(size_t)i] || g->peer0[(size_t)i]) continue;
+            int64_t r0 = lo[(size_t)i];
+            while (r0 < hi[(size_t)i] && rc == ICL_OK) {
+                int64_t r1 = r0 + 1, off0 = 0, c1 = 0, offb = 0, cb = 0;
+                (void)icl_ward_span(lo[(size_t)i], r0, &offb, &cb); // floats of this span before row r0
+                while (r1 < hi[(size_t)i] && icl_ward_span(r0, r1 + 1, &off0, &c1) == ICL_OK && c1 <= (64LL << 20)) ++r1;
+                (void)icl_ward_span(r0, r1, &off0, &c1);
+                if (c1 > land_floats) {
+                    if (land) (void)icl_dev_free(c0, land);
+                    land = nullptr;
+                    rc = icl_dev_malloc(c0, c1 * 4, &land);
+                    land_floats = rc == ICL_OK ? c1 : 0;
+                }
+                if (rc == ICL_OK && c1 > 0) {
+                    icl_device_guard dg(c0->device);
+                    if (hipMemcpyPeer(land, c0->device, dSpan[(size_t)i] + cb, g->ctx[(size_t)i]->device, (size_t)c1 * 4) != hipSuccess)
+                        rc = icl_fail(c0, ICL_ERR_HIP, "copy of distance rows [%lld, %lld) from GPU %d failed", (long long)r0, (long long)r1, g->ctx[(size_t)i]->device);
+                    const float *lp = (const float *)land;
+                    if (rc == ICL_OK) rc = icl_ward_unpack_spans_dev(c0, 1, &r0, &r1, &lp);
+                }
+                r0 = r1;
+            }
+        }
+        if (land) (void)icl_dev_free(c0, land);
         if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
     }
     for (int i = 0; i < parts; ++i)
         if (dSpan[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dSpan[(size_t)i]);
+    if (rc == ICL_OK) {
+        rc = icl_cluster_prefilled_dev(c0, dE[0], n, d, min_size, max_size, update, lo[0], hi[0], cluster_id, member_rank, n_clusters);
+        if (rc != ICL_OK) group_fail(g, rc, icl_last_error(c0));
+    }
     return rc;
 }
 
@@ -217,7 +285,9 @@ extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_
         const int rc = icl_cluster(c0, E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
         return rc == ICL_OK ? rc : group_fail(g, rc, icl_last_error(c0));
     }
-    // E crosses PCIe ONCE (into GPU 0); the other GPUs get it by peer copies (xGMI when the devices are peers)
+    // E crosses PCIe ONCE (into GPU 0); the other GPUs get it by peer copies (xGMI when the devices are peers) -- only when they
+    // compute distance rows
+    const bool deal = group_deals_rows(g);
     std::vector<float *> dE((size_t)parts, nullptr);
     auto cleanup = [&] {
         for (int i = 0; i < parts; ++i)
@@ -225,12 +295,13 @@ extern "C" int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_
     };
     const int64_t ebytes = n * (int64_t)d * 4;
     int rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+        if (i && !deal) return ICL_OK;
         void *p = nullptr;
         ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(ebytes, 16), &p));
         dE[(size_t)i] = (float *)p;
         return i == 0 ? icl_memcpy_h2d(c, p, E, ebytes) : (int)ICL_OK;
     });
-    if (rc == ICL_OK)
+    if (rc == ICL_OK && deal)
         rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
             if (i == 0) return ICL_OK;
             icl_device_guard dg(c->device);
@@ -264,22 +335,28 @@ extern "C" int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int
         *n_clusters = 0;
         return ICL_OK;
     }
-    const bool resident = parts > 1 && update == ICL_UPDATE_EXACT && n >= 2 * 128 * parts && icl_calc_optimal_clusters(n, min_size, max_size, &kk) == ICL_OK;
+    // every GPU needs all of E only when the distance rows are dealt out (icl_group_set_options); otherwise the shards go to GPU 0
+    const bool resident = group_deals_rows(g) && update == ICL_UPDATE_EXACT && n >= 2 * 128 * parts && icl_calc_optimal_clusters(n, min_size, max_size, &kk) == ICL_OK;
     std::vector<float *> dE((size_t)parts, nullptr);
     auto cleanup = [&] {
         for (int i = 0; i < parts; ++i)
             if (dE[(size_t)i]) (void)icl_dev_free(g->ctx[(size_t)i], dE[(size_t)i]);
     };
     const int64_t ebytes = n * (int64_t)d * 4;
-    // 1. every GPU embeds its shard into its own n x 2048 buffer (only GPU 0 needs the full buffer when the rest is not dealt out)
-    int rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+    // 1. every GPU embeds its shard into its own n x 2048 buffer (only GPU 0 needs the full buffer when the rest is not dealt out).
+    // The buffers exist BEFORE the host threads start: the workers of GPUs 1.. copy into GPU 0's buffer in the non-resident path.
+    int rc = ICL_OK;
+    for (int i = 0; i < parts && rc == ICL_OK; ++i)
+        if (i == 0 || resident) {
+            void *p = nullptr;
+            rc = icl_dev_malloc(g->ctx[(size_t)i], std::max<int64_t>(ebytes, 16), &p);
+            dE[(size_t)i] = (float *)p;
+            if (rc != ICL_OK) group_fail(g, rc, std::string("GPU ") + std::to_string(i) + ": " + icl_last_error(g->ctx[(size_t)i]));
+        }
+    if (rc == ICL_OK)
+      rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
         int64_t lo, hi;
         shard_range(n, parts, i, lo, hi);
-        void *p = nullptr;
-        if (i == 0 || resident) {
-            ICL_TRY(icl_dev_malloc(c, std::max<int64_t>(ebytes, 16), &p));
-            dE[(size_t)i] = (float *)p;
-        }
         if (hi == lo) return ICL_OK;
         void *di = nullptr;
         ICL_TRY(icl_dev_malloc(c, (hi - lo) * (int64_t)ICL_IMG_BYTES, &di));

@@ -928,6 +928,15 @@ extern "C" int icl_model_load_blob(icl_ctx *ctx, const void *blob, int64_t bytes
         }
         ICL_TRY(upload(ctx, (void **)&L.scale, sc.data(), (size_t)cout * 4));
         ICL_TRY(upload(ctx, (void **)&L.shift, sh.data(), (size_t)cout * 4));
+        if (i == 0) { // stem2_pool_kernel: [64][kh][8 kw slots][4 channel slots] = bf16(W * scale), zero in the padding
+            std::vector<uint16_t> ws((size_t)64 * ST2_K, 0);
+            for (int co = 0; co < 64; ++co)
+                for (int c = 0; c < 3; ++c)
+                    for (int a = 0; a < 7; ++a)
+                        for (int b = 0; b < 7; ++b)
+                            ws[(size_t)co * ST2_K + (size_t)a * 32 + (size_t)b * 4 + c] = host_bf16(W[(((size_t)co * 3 + c) * 7 + a) * 7 + b] * sc[(size_t)co]);
+            ICL_TRY(upload(ctx, &L.wfold, ws.data(), ws.size() * 2));
+        }
         if (t[i].stage == 1 && t[i].role >= 1 && t[i].role <= 3) { // the fused stage-1 bottleneck takes its BN scales inside the weights
             for (size_t e = 0; e < wf.size(); ++e) wb[e] = host_bf16(wf[e] * sc[e / (size_t)L.K]);
             ICL_TRY(upload(ctx, &L.wfold, wb.data(), wb.size() * 2));
@@ -1217,12 +1226,13 @@ static int launch_conv_fused_ds(icl_ctx *ctx, int prec, const conv_layer &c3, co
 }
 
 // ICL_FUSE (A/B measurements and the fused == unfused tests): bit 0 stem + maxpool in one launch, bit 1 the identity
-// bottlenecks of stage 1 in one launch each, bit 2 stage 1's first bottleneck (downsample branch).  Default: all.
+// bottlenecks of stage 1 in one launch each, bit 2 stage 1's first bottleneck (downsample branch), bit 3 (with bit 0, bf16) the
+// stem that reads its B operand straight from a bf16 patch (stem2_pool_kernel).  Default: all.
 static int fuse_mask()
 {
     static const int m = [] {
         const char *e = getenv("ICL_FUSE");
-        return e ? atoi(e) : 7;
+        return e ? atoi(e) : 15;
     }();
     return m;
 }
@@ -1231,6 +1241,15 @@ template <typename T>
 static void launch_stem_pool(icl_ctx *ctx, int prec, const uint8_t *d_img, int B, void *pooled, hipStream_t strm)
 {
     icl_model *m = ctx->model;
+    if (prec == ICL_PREC_BF16 && (fuse_mask() & 8)) { // no im2col staging: B fragments straight from the bf16 patch
+        const conv_layer &L0 = m->conv[0];
+        icl_prof_scope ps(ctx, ICL_K_CONV64, 2.0 * (double)B * 112 * 112 * 64 * 147, 0.0);
+        const int nunits = B * SP_STRIPS;
+        const int per_cu = std::max<int>(1, std::min<int>(5, (int)((size_t)160 * 1024 / stem2_lds_bytes())));
+        const unsigned grid = (unsigned)std::min<int64_t>(nunits, (int64_t)per_cu * ctx->prop.multiProcessorCount);
+        hipLaunchKernelGGL(stem2_pool_kernel, dim3(grid), dim3(256), stem2_lds_bytes(), strm, d_img, (const uint16_t *)L0.wfold, L0.shift, (uint16_t *)pooled, nunits);
+        return;
+    }
     icl_lds_optin(ctx, (const void *)stem_pool_kernel<T>, (int)stem_pool_lds_bytes<T>());
     conv_args a;
     const conv_layer &L = m->conv[0];
@@ -1257,10 +1276,15 @@ static int launch_bneck56(icl_ctx *ctx, const conv_layer &c1, const conv_layer &
     a.W3 = (const uint16_t *)(ds ? c3.wfused[ICL_PREC_BF16] : c3.wfold);
     a.sh1 = c1.shift; a.sh2 = c2.shift;
     a.sh3 = ds ? c3.shift_fused : c3.shift;
-    a.zero = ctx->model->zero;
     a.B = B; a.H = c2.rec.hin; a.W = c2.rec.hin;
+    if ((int64_t)B * a.H * a.W * 512 >= (1LL << 31)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "fused bottleneck: batch of %d images exceeds the 32-bit buffer offsets", B);
     a.nstrips = (a.W + BN56_COLS - 1) / BN56_COLS;
     a.ngroups = std::max(1, std::min(B, ctx->prop.multiProcessorCount / a.nstrips));
+#ifdef BN56_TIMERS
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) (void)hipMalloc((void **)&dbg, 16 * 8);
+    a.dbg = dbg;
+#endif
     const double px = (double)B * a.H * a.W;
     icl_prof_scope ps(ctx, ICL_K_CONV, 2.0 * px * (64.0 * c1.rec.cin + 64.0 * 576 + 256.0 * (ds ? 128 : 64)), 0.0);
     const dim3 grid((unsigned)(a.nstrips * a.ngroups));
@@ -1272,6 +1296,21 @@ static int launch_bneck56(icl_ctx *ctx, const conv_layer &c1, const conv_layer &
         hipLaunchKernelGGL((bneck56_kernel<false>), grid, dim3(512), bneck56_lds_bytes<false>(), strm, a);
     }
     ICL_HIP(ctx, hipGetLastError());
+#ifdef BN56_TIMERS
+    if (getenv("BN56_PRINT")) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(strm);
+        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+        const char *fn[8] = {"carry+conv1", "wait E", "dma+t1 epi", "wait C", "conv2+t2 epi", "wait x", "wait D", ""};
+        const char *bn[8] = {"t2 reads + side wait", "ST reads + t2 MFMAs", "DMA issue", "side MFMAs + epilogue", "read-back + stores", "barrier waits", "", ""};
+        const int nsteps = ((B / a.ngroups) * (a.H + 1) + 7) / 8;
+        fprintf(stderr, "[bn56 %s] cycles per step (steps %d):\n  front:", ds ? "ds" : "id", nsteps);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f |", fn[k], (double)h[k] / nsteps);
+        fprintf(stderr, "\n  back :");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f |", bn[k], (double)h[8 + k] / nsteps);
+        fprintf(stderr, "\n");
+    }
+#endif
     return ICL_OK;
 }
 
@@ -1392,7 +1431,7 @@ extern "C" int icl_bottleneck56(icl_ctx *ctx, const float *x, int B, int H, int 
     const bool has_ds = wds != nullptr;
     if (has_ds && (!scds || !shds)) return icl_fail(ctx, ICL_ERR_ARG, "icl_bottleneck56: downsample scale / shift missing");
     if (Cin != (has_ds ? 64 : 256)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_bottleneck56: Cin must be 256 (identity) or 64 (downsample branch)");
-    if ((int64_t)B * (H + 1) >= (1LL << 28)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_bottleneck56: too many rows");
+    if ((int64_t)B * H * W * 512 >= (1LL << 31)) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "icl_bottleneck56: tensor exceeds the kernel's 32-bit buffer offsets");
     return no_throw(ctx, "icl_bottleneck56", [&]() -> int {
         std::lock_guard<std::mutex> lk(ctx->mu);
         icl_device_guard g(ctx->device);
@@ -1422,12 +1461,14 @@ extern "C" int icl_bottleneck56(icl_ctx *ctx, const float *x, int B, int H, int 
         if (!rc) rc = upload(ctx, (void **)&d1h, sh1, 64 * 4);
         if (!rc) rc = upload(ctx, (void **)&d2h, sh2, 64 * 4);
         if (!rc) rc = upload(ctx, (void **)&d3h, h3.data(), 256 * 4);
-        if (!rc && (hipMalloc(&dz, 256) != hipSuccess || hipMemset(dz, 0, 256) != hipSuccess)) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_bottleneck56: zero page");
         if (!rc && hipMalloc(&dy, ny * 2) != hipSuccess) rc = icl_fail(ctx, ICL_ERR_NOMEM, "icl_bottleneck56: output alloc");
         if (!rc) {
             bneck_args a;
             a.X = (const uint16_t *)dx; a.Y = (uint16_t *)dy; a.W1 = (const uint16_t *)dw1; a.W2 = (const uint16_t *)dw2; a.W3 = (const uint16_t *)dw3;
-            a.sh1 = d1h; a.sh2 = d2h; a.sh3 = d3h; a.zero = dz;
+            a.sh1 = d1h; a.sh2 = d2h; a.sh3 = d3h;
+#ifdef BN56_TIMERS
+            a.dbg = nullptr;
+#endif
             a.B = B; a.H = H; a.W = W;
             a.nstrips = (W + BN56_COLS - 1) / BN56_COLS;
             a.ngroups = std::max(1, std::min(B, ctx->prop.multiProcessorCount / a.nstrips));

@@ -12,6 +12,57 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, const f32x4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// Raw buffer descriptor over [base, base + bytes): 32-bit byte offsets, and the hardware's range check does the masking -- a lane
+// whose offset is out of range (BN56_OOB) loads nothing that matters and stores nothing, while the INSTRUCTION is still issued, so
+// the number of vector-memory operations between two counted waits is exact and no lane needs an address select.
+#define BN56_OOB 0x80000000u
+__device__ __forceinline__ i32x4_t bn56_srd(const void *base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    i32x4_t r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)(unsigned)(a >> 32);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+// LDS-DMA piece through a descriptor: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS byte address lds_dst; the source of lane l
+// is base + soff + voff(l).  (s_nop 4: the scalar operands were written by SALU instructions the assembler cannot see.)
+__device__ __forceinline__ void bload_lds16_asm(const i32x4_t &srd, unsigned voff, unsigned soff, unsigned lds_dst)
+{
+    unsigned keep;
+    // (readfirstlane: under scalar-register pressure hipcc keeps wave-uniform values in vector registers)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+// one 16-byte store through a descriptor (the trailing s_nop: hipcc may otherwise overwrite the data registers before the store has read them)
+__device__ __forceinline__ void bstore16_asm(const i32x4_t &srd, unsigned voff, unsigned soff, const uint4 &v)
+{
+    const u32x4_t x = __builtin_bit_cast(u32x4_t, v);
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(x), "v"(voff), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+// relu(a), relu(b) rounded to bf16 and packed: ONE v_cvt_pk_bf16_f32 (round to nearest even) and ONE v_pk_max_i16 -- a negative
+// bf16 is a negative int16, so max(., 0) on the packed halves is the ReLU of both (-0 -> +0); rounding is monotonic, so
+// relu-after-round equals round-after-relu bit for bit
+__device__ __forceinline__ uint32_t pack_relu_bf16x2(float a, float b)
+{
+    const f32x2_t f{a, b};
+    const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+    const i16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, h), i16x2_t{0, 0});
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Stem + maxpool.  Work unit = (image, strip): a strip is 16 conv columns (14s-1 .. 14s+14, 15 of them used) =
 // 7 pooled columns, so 8 strips cover the 56 pooled columns (1.14x recompute of the stem along x, none along y).
@@ -250,6 +301,167 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const uint8_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Stem + maxpool, bf16, WITHOUT an im2col staging pass (stem_pool_kernel above cuts every 16-byte A chunk out of the u8 patch
+// again for each of the 128 x 147 products' operands: ~480 vector instructions per thread and tile around 12 MFMAs -- the
+// pass's kernel furthest from its roofline).  Here the input patch is converted ONCE per tile to bf16 pixels padded to four
+// channels (R, G, B, 0: 8 bytes), and the implicit GEMM runs with K ordered (kh, kw padded to 8, channel padded to 4) = 7 k-steps
+// of 32: the B operand of v_mfma_f32_16x16x32_bf16 for conv pixel (oy, ox), k-step kh, lane quarter q is the 16 bytes
+//   patch[2 oy + kh][2 ox + 2q .. 2 ox + 2q + 1][0..3],
+// contiguous and 16-byte aligned for every lane -- read straight from the patch, each patch row fragment once per tile and used
+// by up to four (oy, kh) pairs.  The weights (64 x 224, BatchNorm scale folded in, zero in the padding) sit in registers: wave w
+// owns the output channels 16w .. 16w+15 for all 128 pixels of a tile; the shift is the accumulator's initial value.
+// Tile walk, carried conv row and pooling as in stem_pool_kernel.  Pixels are byte / 255 rounded to bf16, as before.
+// ------------------------------------------------------------------------------------------------------------
+#define ST2_K 224            /* 7 filter rows x 8 kw slots x 4 channel slots */
+#define ST2_PW 40            /* patch row: 37 pixels used (+ the kw padding's reach), 8 bytes each */
+#define ST2_RAWW 120         /* raw u8 patch row stride (as STEM_PW) */
+static constexpr size_t stem2_lds_bytes()
+{
+    // [raw u8 patch][bf16 RGBX patch: 21 rows + 1 of slack][pool tile: 8 x 16 conv pixels x 64 channels][2 carried conv rows]
+    return (size_t)((STEM_PH * ST2_RAWW + 16 + 15) & ~15) + (size_t)(STEM_PH + 1) * ST2_PW * 8 + (size_t)128 * 128 + 2 * 16 * 128;
+}
+
+__global__ __launch_bounds__(256) void stem2_pool_kernel(const uint8_t *__restrict__ img, const uint16_t *__restrict__ W2k /* [64][224] */,
+                                                        const float *__restrict__ shift, uint16_t *__restrict__ Yg /* [B][56][56][64] */, int nunits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RAWB = (STEM_PH * ST2_RAWW + 16 + 15) & ~15;
+    unsigned char *raw = smem;
+    unsigned char *pbf = smem + RAWB;                            // [22][40] pixels x 8 bytes
+    unsigned char *ptile = pbf + (STEM_PH + 1) * ST2_PW * 8;     // [128 pixels][128 B], 16-byte slots XOR-swizzled by (pixel >> 1) & 7
+    unsigned char *carry = ptile + 128 * 128;                    // [2][16 pixels][128 B], same swizzle
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    uint4 wr[7];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) wr[kh] = *reinterpret_cast<const uint4 *>(W2k + (size_t)(16 * w + r16) * ST2_K + 32 * kh + 8 * q);
+    const float4 hf = *reinterpret_cast<const float4 *>(shift + 16 * w + 4 * q);
+    const f32x4 hv = f32x4{hf.x, hf.y, hf.z, hf.w};
+    const int swc = (r16 >> 1) & 7;
+    const unsigned boff = (unsigned)((2 * r16 + 2 * q) * 8);     // this lane's B fragment inside a patch row
+    const unsigned toff = (unsigned)(r16 * 128 + ((((2 * w + (q >> 1)) ^ swc) & 7) << 4) + 8 * (q & 1));
+    // raw patch of tile (unit = image * 8 + strip, t), fetched as aligned dwords (stem_pool_kernel's scheme)
+    constexpr int RW = ST2_RAWW / 4, NDW = STEM_PH * RW + 4, NV = (NDW + 255) / 256;
+    uint32_t pv[NV];
+    auto patch_fetch = [&](int unit, int t) {
+        const uint8_t *ib = img + (int64_t)(unit >> 3) * (int64_t)ICL_IMG_BYTES;
+        const int iy0 = t * 16 - 3, bx0 = 84 * (unit & 7) - 16;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + k * 256;
+            const int pr = i / RW, pc = i - pr * RW;
+            const int iy = iy0 + pr, bx = bx0 + pc * 4;
+            const bool ok = i < NDW && pr < STEM_PH && (unsigned)iy < 224u && (unsigned)bx < 672u;
+            pv[k] = ok ? *reinterpret_cast<const uint32_t *>(ib + iy * 672 + bx) : 0u;
+        }
+    };
+    auto patch_store = [&]() {
+        uint32_t *p32 = reinterpret_cast<uint32_t *>(raw);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + k * 256;
+            if (i < NDW) p32[i] = pv[k];
+        }
+    };
+    const float sc255 = (float)(1.0 / 255.0);
+    auto convert = [&]() { // raw bytes -> bf16 RGBX pixels (the raw patch starts 1 byte left of the tile's first pixel)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * 256;
+            if (i < STEM_PH * ST2_PW) {
+                const int pr = i / ST2_PW, pc = i - pr * ST2_PW;
+                uint2 o = make_uint2(0u, 0u);
+                if (pc < 38) {
+                    const int addr = pr * ST2_RAWW + pc * 3 + 1;
+                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(raw + (addr & ~3));
+                    const uint32_t v3 = __builtin_amdgcn_alignbyte(w32[1], w32[0], addr & 3);
+                    const float r = (float)(v3 & 0xffu) * sc255, g = (float)((v3 >> 8) & 0xffu) * sc255, b = (float)((v3 >> 16) & 0xffu) * sc255;
+                    o.x = (uint32_t)BF16::from_f(r) | ((uint32_t)BF16::from_f(g) << 16);
+                    o.y = (uint32_t)BF16::from_f(b);
+                }
+                *reinterpret_cast<uint2 *>(pbf + i * 8) = o;
+            }
+        }
+    };
+    int unit = blockIdx.x, t = 0;
+    if (unit >= nunits) return;
+    if (tid < ST2_PW) *reinterpret_cast<uint2 *>(pbf + (STEM_PH * ST2_PW + tid) * 8) = make_uint2(0u, 0u); // the slack row
+    patch_fetch(unit, t);
+    patch_store();
+    __syncthreads();
+    for (;;) {
+        int nt = t + 1, nu = unit;
+        if (nt == SP_TILES) {
+            nt = 0;
+            nu = unit + (int)gridDim.x;
+        }
+        const bool has_next = nu < nunits; // workgroup-uniform
+        convert();
+        if (has_next) patch_fetch(nu, nt); // in flight while this tile is computed
+        __syncthreads();                   // the bf16 patch is complete; the raw patch may be overwritten
+        if (has_next) patch_store();
+        // ---- conv0: 8 output rows x 16 columns x this wave's 16 channels; patch row r feeds (oy, kh) with 2 oy + kh = r
+        f32x4 acc[8];
+#pragma unroll
+        for (int r = 0; r < STEM_PH; ++r) {
+            const uint4 bf = *reinterpret_cast<const uint4 *>(pbf + r * (ST2_PW * 8) + boff);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int kh = r - 2 * m;
+                if (kh >= 0 && kh < 7) acc[m] = mfma16(wr[kh], bf, kh == 0 ? hv : acc[m]);
+            }
+        }
+        // ---- ReLU, rounded, into the pool tile; the tile's last conv row also goes to the carry buffer of the next tile
+        unsigned char *carry_cur = carry + (t & 1) * 2048, *carry_nxt = carry + ((t + 1) & 1) * 2048;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            uint2 o;
+            o.x = pack_relu_bf16x2(acc[m][0], acc[m][1]);
+            o.y = pack_relu_bf16x2(acc[m][2], acc[m][3]);
+            *reinterpret_cast<uint2 *>(ptile + m * 2048 + toff) = o;
+            if (m == 7) *reinterpret_cast<uint2 *>(carry_nxt + toff) = o;
+        }
+        __syncthreads(); // the pool tile is complete
+        // ---- maxpool 3x3/2 p1 (padding never wins): pooled rows 4t .. 4t+3, pooled columns 7s .. 7s+6; one 16-byte chunk per thread
+        if (tid < 28 * 8) {
+            const int s = unit & 7;
+            const int64_t b = unit >> 3;
+            const int ch = tid & 7, pix = tid >> 3, pr = pix / 7, pc = pix - 7 * pr;
+            float best[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int rr = 2 * pr + kh; // 0: the carried conv row 8t-1; 1 .. 8: this tile's rows
+                if (rr == 0 && t == 0) continue;
+                const unsigned char *rowp = rr == 0 ? carry_cur : ptile + (rr - 1) * 2048;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ci = 2 * pc + kw; // conv column 14s - 1 + ci
+                    if (s == 0 && ci == 0) continue;
+                    const uint4 rawv = *reinterpret_cast<const uint4 *>(rowp + ci * 128 + (((ch ^ (ci >> 1)) & 7) << 4));
+                    const uint16_t *pvv = reinterpret_cast<const uint16_t *>(&rawv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = BF16::to_f(pvv[e]);
+                        if (f > best[e]) best[e] = f;
+                    }
+                }
+            }
+            uint16_t o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = BF16::from_f(best[e]);
+            *reinterpret_cast<uint4 *>(Yg + ((b * 56 + 4 * t + pr) * 56 + 7 * s + pc) * 64 + ch * 8) = *reinterpret_cast<const uint4 *>(o);
+        }
+        if (!has_next) break;
+        unit = nu;
+        t = nt;
+        __syncthreads(); // the next raw patch is in LDS; the pool tile is free again
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // One stage-1 bottleneck per launch (bf16):  y = relu(bn3(conv3(relu(bn2(conv2_3x3(relu(bn1(conv1(x))))))) + x)           [identity]
 //                                            y = relu(bn3(conv3(t2)) + bn_ds(conv_ds(x)))                               [DS: block 0]
 // mid = 64 channels, Cout = 256, Cin = 256 (identity) or 64 (DS); any H, W.  Every BatchNorm scale is folded into the bf16
@@ -276,6 +488,29 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const uint8_t *__restric
 //   k order per output element: channels ascending for the 1x1s, (row, kw, channel) for the 3x3, [t2 | x] for DS: fixed,
 //   so results do not depend on the batch or on the strip decomposition.
 // ------------------------------------------------------------------------------------------------------------
+// in-kernel segment timers for tuning (a separate diagnostic build: -DBN56_TIMERS; scratch/bn56_timers.py prints them)
+#ifdef BN56_TIMERS
+#define BN56_STAMP(k)                                                                              \
+    do {                                                                                           \
+        unsigned long long t__;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        tacc[k] += t__ - tlast;                                                                    \
+        tlast = t__;                                                                               \
+    } while (0)
+#define BN56_TIMER_DECL unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0
+#define BN56_TIMER_START asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory")
+#define BN56_TIMER_FLUSH(role)                                                                     \
+    if (p.dbg && blockIdx.x == 0 && w == 0 && lane == 0)                                            \
+        for (int k__ = 0; k__ < 8; ++k__) p.dbg[(role)*8 + k__] = tacc[k__]
+#else
+#define BN56_STAMP(k)
+#define BN56_TIMER_DECL
+#define BN56_TIMER_START
+#define BN56_TIMER_FLUSH(role)
+#endif
+
 struct bneck_args {
     const uint16_t *X;  // [B][H][W][CIN]
     uint16_t *Y;        // [B][H][W][256]
@@ -283,9 +518,11 @@ struct bneck_args {
     const uint16_t *W2; // [64][3][3][64]   * scale2
     const uint16_t *W3; // identity: [256][64] * scale3; DS: [256][64 + 64] = [W3*scale3 | Wds*scale_ds]
     const float *sh1, *sh2, *sh3; // folded BN shifts (DS: sh3 = shift3 + shift_ds)
-    const void *zero;   // >= 16 zero bytes
-    int B, H, W;
+    int B, H, W;        // (B * H * W * 256 * 2 bytes < 2^31: 32-bit buffer offsets)
     int nstrips, ngroups; // grid = nstrips * ngroups; group g owns the images [g*B/ngroups, (g+1)*B/ngroups)
+#ifdef BN56_TIMERS
+    unsigned long long *dbg; // [2 roles][8 segments] cycles of workgroup 0 (front wave 0, back wave 4)
+#endif
 };
 
 #define BN56_COLS 14                         /* output columns per strip */
@@ -295,28 +532,22 @@ struct bneck_args {
 template <bool DS>
 static constexpr size_t bneck56_lds_bytes()
 {
-    return (size_t)(DS ? 1 : 4) * 128 * 128 + BN56_T1_BYTES + 2 * BN56_T2_BYTES;
+    return (size_t)(DS ? 1 : 4) * 128 * 128 + BN56_T1_BYTES + 2 * BN56_T2_BYTES + 4 * 8192; // x tile, t1, t2[2], the back waves' side / output tiles
 }
 
-__device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, const f32x4 &c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
-{
-    return (uint32_t)BF16::from_f(a) | ((uint32_t)BF16::from_f(b) << 16);
-}
 // workgroup barrier that waits for this wave's LDS traffic only (the front waves' LDS-DMA stays in flight across it; their own
 // counted wait covers it before the barrier that publishes the tile)
 __device__ __forceinline__ void bn56_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // (image, row) of a virtual row cursor, advanced without divisions (VH = H + 1 rows per image, row H = padding)
 struct bn56_row {
-    int b, r;
+    int b, r, p; // image, row inside the image (H = the padding row), physical row b * H + r of the tensor
     __device__ __forceinline__ void step(int VH)
     {
+        ++p;
         if (++r == VH) {
             r = 0;
             ++b;
+            --p; // the padding row is not in memory
         }
     }
 };
@@ -348,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void bneck56_kernel(const bneck_args p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xoff[ks] = (unsigned)(r16 * 128 + ((((4 * ks + q) ^ swc) & 7) << 4));
 
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (wid < 4) {
         // =========================================== front waves: conv1, conv2 ===========================================
         uint4 w1r[NCH * 2], w2r[18];
@@ -355,7 +587,8 @@ __global__ __launch_bounds__(512, 2) void bneck56_kernel(const bneck_args p)
         for (int kk = 0; kk < NCH * 2; ++kk) w1r[kk] = *reinterpret_cast<const uint4 *>(p.W1 + (size_t)(16 * w + r16) * CIN + 32 * kk + 8 * q);
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) w2r[kk] = *reinterpret_cast<const uint4 *>(p.W2 + (size_t)(16 * w + r16) * 576 + 32 * kk + 8 * q);
-        const float4 h1 = *reinterpret_cast<const float4 *>(p.sh1 + 16 * w + 4 * q), h2 = *reinterpret_cast<const float4 *>(p.sh2 + 16 * w + 4 * q);
+        const float4 h1f = *reinterpret_cast<const float4 *>(p.sh1 + 16 * w + 4 * q), h2f = *reinterpret_cast<const float4 *>(p.sh2 + 16 * w + 4 * q);
+        const f32x4 h1 = f32x4{h1f.x, h1f.y, h1f.z, h1f.w}, h2 = f32x4{h2f.x, h2f.y, h2f.z, h2f.w}; // the shifts: C operand of a chain's first MFMA
         unsigned t1off[3][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -370,51 +603,65 @@ __global__ __launch_bounds__(512, 2) void bneck56_kernel(const bneck_args p)
         // LDS-DMA roles: wave w fills the tile rows 2w, 2w+1 (pieces of 8 pixels x 128 B): piece i of a row = columns 8i ..
         const int dcol = lane >> 3, dps = lane & 7;
         const unsigned xt_wave = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)w * 4096u);
-        int dcoff[2]; // element offset of this lane's source chunk inside an image row, or -1: column outside the image
+        const i32x4_t xsrd = bn56_srd(p.X, (unsigned)((size_t)p.B * H * Wd * CIN * 2));
+        const unsigned xrow_bytes = (unsigned)(Wd * CIN * 2);
+        unsigned dvoff[2]; // byte offset of this lane's source chunk inside an image row (channel chunk 0), or out of range: column outside the image
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = 8 * i + dcol, col = c0 - 1 + c;
-            dcoff[i] = (unsigned)col < (unsigned)Wd ? col * CIN + ((dps ^ (c >> 1)) & 7) * 8 : -1;
+            dvoff[i] = (unsigned)col < (unsigned)Wd ? (unsigned)(col * CIN + ((dps ^ (c >> 1)) & 7) * 8) * 2u : BN56_OOB;
         }
         auto stage_x = [&](bn56_row t) { // the tile rows 2w, 2w+1 of the x tile whose row 2w is the virtual row t
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const bool rok = t.b < b1 && t.r < H;
-                const uint16_t *rowp = p.X + ((size_t)t.b * H + t.r) * (size_t)Wd * CIN;
+                const unsigned soff = rok ? (unsigned)t.p * xrow_bytes : 0u;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned vo = rok ? dvoff[i] : BN56_OOB;
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) {
-                        const void *src = (rok && dcoff[i] >= 0) ? (const void *)(rowp + dcoff[i] + 64 * ch) : p.zero;
-                        glds16_asm(src, xt_wave + (unsigned)(ch * 16384 + (2 * rr + i) * 1024));
-                    }
+                    for (int ch = 0; ch < NCH; ++ch) bload_lds16_asm(xsrd, vo, soff + (unsigned)(128 * ch), xt_wave + (unsigned)(ch * 16384 + (2 * rr + i) * 1024));
+                }
                 t.step(VH);
             }
         };
-        bn56_row cur{b0, 0}; // virtual row S + 8j: the first new t1 row of step j
-        bn56_row dma = cur;  // ... + 2w: this wave's first DMA row
+        bn56_row cur{b0, 0, b0 * H}; // virtual row S + 8j: the first new t1 row of step j
+        bn56_row dma = cur;          // ... + 2w: this wave's first DMA row
         for (int i = 0; i < 2 * w; ++i) dma.step(VH);
-        if (tid < 256) reinterpret_cast<uint4 *>(T1)[tid] = make_uint4(0, 0, 0, 0); // the two kept t1 rows of step 0: padding
+        reinterpret_cast<uint4 *>(T1)[tid] = make_uint4(0, 0, 0, 0); // the two kept t1 rows of step 0: padding
         stage_x(dma);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bn56_barrier(); // D
+        BN56_TIMER_DECL;
+        BN56_TIMER_START;
+#pragma unroll 1
         for (int j = 0; j < nsteps; ++j) {
-            // keep the last two t1 rows of the previous step (rows 8, 9 -> 0, 1: same swizzle, the pixel index moves by 128)
-            if (j > 0) reinterpret_cast<uint4 *>(T1)[tid] = reinterpret_cast<const uint4 *>(T1 + 16384)[tid];
-            // ---- conv1: t1[rows 2..9] = relu(W1' . x + shift1)
+            // ---- conv1: t1[rows 2..9] = relu(W1' . x + shift1).  The 8 B fragments of the next k-step are requested before the
+            // MFMAs of this one (alone, hipcc keeps two fragments in flight and every MFMA group waits out an LDS round trip)
             f32x4 a1[8];
+            {
+                // units of 4 fragments (one k-step, four tile rows), requested two units ahead of their MFMAs
+                constexpr int NU = NCH * 4;
+                uint4 f[3][4];
+                auto ld = [&](int u, uint4 (&d)[4]) {
+                    const int kk = u >> 1, m0 = 4 * (u & 1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a1[m] = f32x4{h1.x, h1.y, h1.z, h1.w};
+                    for (int m = 0; m < 4; ++m) d[m] = *reinterpret_cast<const uint4 *>(XT + (kk >> 1) * 16384 + (m0 + m) * 2048 + xoff[kk & 1]);
+                };
+                ld(0, f[0]);
+                ld(1, f[1]);
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
+                for (int u = 0; u < NU; ++u) {
+                    if (u + 2 < NU) ld(u + 2, f[(u + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int kk = u >> 1, m0 = 4 * (u & 1);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const uint4 bf = *reinterpret_cast<const uint4 *>(XT + ch * 16384 + m * 2048 + xoff[ks]);
-                        a1[m] = mfma16(w1r[ch * 2 + ks], bf, a1[m]);
-                    }
+                    for (int m = 0; m < 4; ++m) a1[m0 + m] = mfma16(w1r[kk], f[u % 3][m], kk == 0 ? h1 : a1[m0 + m]);
+                }
+            }
+            BN56_STAMP(0); // conv1
             bn56_barrier(); // E: every front wave has read the x tile; the kept rows are in place
+            BN56_STAMP(1); // wait at E
             for (int i = 0; i < 8; ++i) dma.step(VH);
             if (j + 1 < nsteps) stage_x(dma);
             {
@@ -423,153 +670,220 @@ __global__ __launch_bounds__(512, 2) void bneck56_kernel(const bneck_args p)
                 for (int m = 0; m < 8; ++m) {
                     const bool ok = t.b < b1 && t.r < H && col_in; // conv2 pads t1 with zeros, not with relu(shift1)
                     uint2 o;
-                    o.x = ok ? pack_bf16x2(fmaxf(a1[m][0], 0.f), fmaxf(a1[m][1], 0.f)) : 0u;
-                    o.y = ok ? pack_bf16x2(fmaxf(a1[m][2], 0.f), fmaxf(a1[m][3], 0.f)) : 0u;
+                    o.x = ok ? pack_relu_bf16x2(a1[m][0], a1[m][1]) : 0u;
+                    o.y = ok ? pack_relu_bf16x2(a1[m][2], a1[m][3]) : 0u;
                     *reinterpret_cast<uint2 *>(T1 + (2 + m) * 2048 + toff) = o;
                     t.step(VH);
                 }
                 cur = t;
             }
+            BN56_STAMP(2); // DMA issue + t1 epilogue
             bn56_barrier(); // C: t1 rows 2..9 are written
-            // ---- conv2: t2 = relu(W2' * t1 + shift2): every t1 fragment (row R, kw, k half) is read once and feeds the taps kh = R - m
+            BN56_STAMP(3); // wait at C
+            // ---- conv2: t2 = relu(W2' * t1 + shift2): every t1 fragment (row R, kw, k half) is read once and feeds the taps kh = R - m;
+            // the 6 fragments of row R + 1 are requested before the MFMAs of row R
             f32x4 a2[8];
+            {
+                // units of 3 fragments (t1 row R, k half ks, kw = 0..2: up to 9 MFMAs), requested one unit ahead
+                uint4 f[2][3];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a2[m] = f32x4{h2.x, h2.y, h2.z, h2.w};
+                for (int kw = 0; kw < 3; ++kw) f[0][kw] = *reinterpret_cast<const uint4 *>(T1 + t1off[kw][0]);
 #pragma unroll
-            for (int R = 0; R < 10; ++R)
+                for (int u = 0; u < 20; ++u) {
+                    const int R = u >> 1, ks = u & 1;
+                    if (u + 1 < 20) {
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                        for (int kw = 0; kw < 3; ++kw) f[(u + 1) & 1][kw] = *reinterpret_cast<const uint4 *>(T1 + ((u + 1) >> 1) * 2048 + t1off[kw][(u + 1) & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const uint4 bf = *reinterpret_cast<const uint4 *>(T1 + R * 2048 + t1off[kw][ks]);
+                    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh) {
                             const int m = R - kh;
-                            if (m >= 0 && m < 8) a2[m] = mfma16(w2r[(kh * 3 + kw) * 2 + ks], bf, a2[m]);
+                            if (m >= 0 && m < 8) a2[m] = mfma16(w2r[(kh * 3 + kw) * 2 + ks], f[u & 1][kw], (kh == 0 && kw == 0 && ks == 0) ? h2 : a2[m]);
                         }
-                    }
+                }
+            }
             unsigned char *T2w = T2 + (j & 1) * BN56_T2_BYTES;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 uint2 o;
-                o.x = pack_bf16x2(fmaxf(a2[m][0], 0.f), fmaxf(a2[m][1], 0.f));
-                o.y = pack_bf16x2(fmaxf(a2[m][2], 0.f), fmaxf(a2[m][3], 0.f));
+                o.x = pack_relu_bf16x2(a2[m][0], a2[m][1]);
+                o.y = pack_relu_bf16x2(a2[m][2], a2[m][3]);
                 *reinterpret_cast<uint2 *>(T2w + m * 2048 + toff) = o;
             }
+            BN56_STAMP(4); // conv2 + t2 epilogue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the next x tile have landed
+            BN56_STAMP(5); // wait for the x tile
             bn56_barrier(); // D: t2[j & 1] and the next x tile are complete; every front wave has read t1
+            BN56_STAMP(6); // wait at D
+            // keep the last two t1 rows for the next step (rows 8, 9 -> 0, 1: same swizzle, the pixel index moves by 128); the next
+            // step's t1 rows are written behind its barrier E
+            reinterpret_cast<uint4 *>(T1)[tid] = reinterpret_cast<const uint4 *>(T1 + 16384)[tid];
         }
+        BN56_TIMER_FLUSH(0);
         // the back waves still work on the last step: join its two barriers (E, C)
         bn56_barrier();
         bn56_barrier();
     } else {
         // =========================================== back waves: conv3 + residual / downsample + ReLU + stores ===========================================
-        uint4 w3r[4 * (K3 / 32)];
+        // A wave works on QUARTERS of a step's tile (2 rows = 32 pixels) through two wave-private LDS tiles of [32 pixels][128 B]:
+        //   ST  the operand that comes from global memory for those pixels -- identity: the residual x[pixel][64w .. 64w+63];
+        //       DS: x[pixel][0 .. 63], the downsample branch's B operand -- brought in by LDS-DMA (pieces of 8 pixels x 128 B:
+        //       every piece is 8 whole 128-byte lines), one quarter ahead.  Both enter the accumulator through the matrix core: DS
+        //       with the downsample weights, identity with a 0 / 1 selector as the A operand (x * 1.0 + acc in fp32 is the plain
+        //       fp32 add, and it costs one MFMA per 16 x 16 outputs instead of 2 vector instructions per output);
+        //   OT  the quarter's outputs, written in the accumulator layout (8 bytes per lane) and read back as 16-byte chunks with 8
+        //       consecutive lanes on one pixel's 128 bytes, so every global store instruction covers 8 whole lines.
+        // (With the accumulator layout on the global side -- adjacent lanes on pixels 512 B apart, 8 bytes each -- the CU's
+        // address path took 64 line look-ups per instruction and 6 000 cycles per step segment: stamped)
+        constexpr int NW3 = DS ? 4 : 2; // k-steps of conv3's weights per 16-channel group: [t2 | x] or t2
+        uint4 w3r[4 * NW3];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int ks = 0; ks < K3 / 32; ++ks)
-                w3r[g * (K3 / 32) + ks] = *reinterpret_cast<const uint4 *>(p.W3 + (size_t)(64 * w + 16 * g + r16) * K3 + 32 * ks + 8 * q);
-        float4 h3[4];
+            for (int ks = 0; ks < NW3; ++ks)
+                w3r[g * NW3 + ks] = *reinterpret_cast<const uint4 *>(p.W3 + (size_t)(64 * w + 16 * g + r16) * K3 + 32 * ks + 8 * q);
+        uint4 sel[2]; // identity: A operand that copies channel 16h + i of a 32-channel k-step into output row i
 #pragma unroll
-        for (int g = 0; g < 4; ++g) h3[g] = *reinterpret_cast<const float4 *>(p.sh3 + 64 * w + 16 * g + 4 * q);
-        const bool col_out = r16 < BN56_COLS && c0 + r16 < Wd; // output column of this lane exists
-        // operand of an output pixel that comes from global memory: the residual chunks (identity: 4 x 8 bytes) or the downsample
-        // branch's B fragments (DS: 2 x 16 bytes)
-        struct side_t {
-            uint4 v[2];
-        };
-        bn56_row out{b0 - 1, H}; // virtual row S - 1 (the padding row above the run): the first output row of step 0
-        auto load_side = [&](const bn56_row &t0, side_t (&sd)[4], bool active) { // the 4 rows from t0 on
-            bn56_row t = t0;
+        for (int h = 0; h < 2; ++h) {
+            uint32_t e[4];
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                const bool ok = active && t.b >= b0 && t.b < b1 && t.r < H && col_out;
-                const size_t pix = ((size_t)t.b * H + t.r) * (size_t)Wd + c0 + r16;
-                if constexpr (DS) {
+            for (int d2 = 0; d2 < 4; ++d2) e[d2] = ((8 * q + 2 * d2 == 16 * h + r16) ? 0x3F80u : 0u) | ((8 * q + 2 * d2 + 1 == 16 * h + r16) ? 0x3F800000u : 0u);
+            sel[h] = make_uint4(e[0], e[1], e[2], e[3]);
+        }
+        f32x4 h3[4];
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-                        sd[mm].v[ks] = *reinterpret_cast<const uint4 *>(ok ? p.X + pix * 64 + 32 * ks + 8 * q : (const uint16_t *)p.zero);
-                } else {
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4 *>(p.sh3 + 64 * w + 16 * g + 4 * q);
+            h3[g] = f32x4{t.x, t.y, t.z, t.w};
+        }
+        unsigned char *ST = T2 + 2 * BN56_T2_BYTES + w * 8192, *OT = ST + 4096;
+        const unsigned st_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(ST));
+        // accumulator-layout offsets inside a quarter tile: pixel (mm, r16), this lane's 4 channels 16g + 4q ..
+        unsigned aoff[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint2 rv = *reinterpret_cast<const uint2 *>(ok ? p.X + pix * 256 + 64 * w + 16 * g + 4 * q : (const uint16_t *)p.zero);
-                        if (g & 1) { sd[mm].v[g >> 1].z = rv.x; sd[mm].v[g >> 1].w = rv.y; }
-                        else { sd[mm].v[g >> 1].x = rv.x; sd[mm].v[g >> 1].y = rv.y; }
-                    }
-                }
+        for (int g = 0; g < 4; ++g) aoff[g] = (unsigned)(r16 * 128 + ((((2 * g + (q >> 1)) ^ swc) & 7) << 4) + 8 * (q & 1));
+        // line-layout roles (DMA pieces and the output read-back): lane -> pixel column 8i + (lane >> 3), physical 16-byte slot lane & 7
+        const int lcol = lane >> 3, lps = lane & 7;
+        const i32x4_t xsrd = bn56_srd(p.X, (unsigned)((size_t)p.B * H * Wd * CIN * 2)), ysrd = bn56_srd(p.Y, (unsigned)((size_t)p.B * H * Wd * 256 * 2));
+        const unsigned xrow_bytes = (unsigned)(Wd * CIN * 2), yrow_bytes = (unsigned)(Wd * 256 * 2);
+        const unsigned xbase = (unsigned)((c0 * CIN + (DS ? 0 : 64 * w)) * 2), ybase = (unsigned)((c0 * 256 + 64 * w) * 2);
+        unsigned xvoff[2], yvoff[2]; // this lane's byte offsets from a row's first strip pixel: source chunk / destination chunk (out of range: no such output column)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = 8 * i + lcol, chunk = (lps ^ (c >> 1)) & 7;
+            const bool ok = c < BN56_COLS && c0 + c < Wd;
+            xvoff[i] = ok ? (unsigned)(c * CIN + chunk * 8) * 2u : BN56_OOB;
+            yvoff[i] = ok ? (unsigned)(c * 256 + chunk * 8) * 2u : BN56_OOB;
+        }
+        auto row_ok = [&](const bn56_row &t) { return t.b >= b0 && t.b < b1 && t.r < H; };
+        auto stage_side = [&](bn56_row t) { // the quarter whose first row is t -> ST (4 pieces)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const bool rok = row_ok(t);
+                const unsigned soff = rok ? (unsigned)t.p * xrow_bytes + xbase : 0u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bload_lds16_asm(xsrd, rok ? xvoff[i] : BN56_OOB, soff, st_lds + (unsigned)((2 * mm + i) * 1024));
                 t.step(VH);
             }
         };
-        auto half = [&](const unsigned char *T2r, int hh, const bn56_row &t0, const side_t (&sd)[4]) { // output rows t0 .. t0+3 = tile rows 4hh ..
-            f32x4 a3[4][4];
+        BN56_TIMER_DECL;
+        auto quarter = [&](const unsigned char *T2q, bn56_row t0, bn56_row tnext) { // T2q: the quarter's two t2 rows
+            uint4 tb[2][2], xb[2][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm) {
+                for (int ks = 0; ks < 2; ++ks) tb[mm][ks] = *reinterpret_cast<const uint4 *>(T2q + mm * 2048 + xoff[ks]);
+            // the side operand of this quarter has landed once only the 4 stores of the previous quarter are younger
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            BN56_STAMP(0); // t2 fragment reads + wait for the side operand
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xb[mm][ks] = *reinterpret_cast<const uint4 *>(ST + mm * 2048 + xoff[ks]);
+            f32x4 a3[4][2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    a3[g][mm] = mfma16(w3r[g * NW3 + 0], tb[mm][0], h3[g]); // shift: the chain's C operand
+                    a3[g][mm] = mfma16(w3r[g * NW3 + 1], tb[mm][1], a3[g][mm]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ST is read: the next quarter's side operand may land
+            __builtin_amdgcn_sched_barrier(0);
+            BN56_STAMP(1); // ST reads + the t2 part's MFMAs
+            stage_side(tnext); // (rows beyond the run: every lane out of range, the instruction count stays exact)
+            BN56_STAMP(2); // DMA issue
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
                     if constexpr (DS) {
-                        a3[g][mm] = f32x4{h3[g].x, h3[g].y, h3[g].z, h3[g].w};
-                    } else { // shift + residual: the accumulator's initial value
-                        const uint32_t lo = (g & 1) ? sd[mm].v[g >> 1].z : sd[mm].v[g >> 1].x, hi = (g & 1) ? sd[mm].v[g >> 1].w : sd[mm].v[g >> 1].y;
-                        a3[g][mm] = f32x4{h3[g].x + __uint_as_float(lo << 16), h3[g].y + __uint_as_float(lo & 0xffff0000u),
-                                          h3[g].z + __uint_as_float(hi << 16), h3[g].w + __uint_as_float(hi & 0xffff0000u)};
+                        a3[g][mm] = mfma16(w3r[g * NW3 + 2], xb[mm][0], a3[g][mm]);
+                        a3[g][mm] = mfma16(w3r[g * NW3 + 3], xb[mm][1], a3[g][mm]);
+                    } else {
+                        a3[g][mm] = mfma16(sel[g & 1], xb[mm][g >> 1], a3[g][mm]); // + residual
                     }
                 }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm) {
-                    const uint4 bf = *reinterpret_cast<const uint4 *>(T2r + (4 * hh + mm) * 2048 + xoff[ks]);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) a3[g][mm] = mfma16(w3r[g * (K3 / 32) + ks], bf, a3[g][mm]);
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack_relu_bf16x2(a3[g][mm][0], a3[g][mm][1]);
+                    o.y = pack_relu_bf16x2(a3[g][mm][2], a3[g][mm][3]);
+                    *reinterpret_cast<uint2 *>(OT + mm * 2048 + aoff[g]) = o;
                 }
-            if constexpr (DS) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) a3[g][mm] = mfma16(w3r[g * (K3 / 32) + 2 + ks], sd[mm].v[ks], a3[g][mm]);
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's OT writes are done (the tile is private to the wave)
+            __builtin_amdgcn_sched_barrier(0);
+            BN56_STAMP(3); // side part's MFMAs + epilogue into OT
             bn56_row t = t0;
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                if (t.b >= b0 && t.b < b1 && t.r < H && col_out) {
-                    uint16_t *dst = p.Y + (((size_t)t.b * H + t.r) * (size_t)Wd + c0 + r16) * 256 + 64 * w + 4 * q;
+            for (int mm = 0; mm < 2; ++mm) {
+                const bool rok = row_ok(t);
+                const unsigned soff = rok ? (unsigned)t.p * yrow_bytes + ybase : 0u;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint2 o;
-                        o.x = pack_bf16x2(fmaxf(a3[g][mm][0], 0.f), fmaxf(a3[g][mm][1], 0.f));
-                        o.y = pack_bf16x2(fmaxf(a3[g][mm][2], 0.f), fmaxf(a3[g][mm][3], 0.f));
-                        *reinterpret_cast<uint2 *>(dst + 16 * g) = o;
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(OT + (2 * mm + i) * 1024 + lane * 16);
+                    bstore16_asm(ysrd, rok ? yvoff[i] : BN56_OOB, soff, v);
                 }
                 t.step(VH);
             }
+            BN56_STAMP(4); // OT read-back + stores
         };
-        side_t s0[4], s1[4];
+        bn56_row out{b0 - 1, H, b0 * H}; // virtual row S - 1 (the padding row above the run): the first output row of step 0
         bn56_barrier(); // D (prologue)
-        // iteration 0: the front waves compute step 0; request the first half's side operands of step 0 meanwhile
+        // iteration 0: the front waves compute step 0; request the first quarter's side operand meanwhile
+        stage_side(out);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bstore16_asm(ysrd, BN56_OOB, 0u, make_uint4(0, 0, 0, 0)); // the first quarter's counted wait expects 4 stores behind its DMA
         bn56_barrier(); // E
-        load_side(out, s0, true);
         bn56_barrier(); // C
         bn56_barrier(); // D: t2[0] is complete
+        BN56_TIMER_START;
+#pragma unroll 1
         for (int j = 1; j <= nsteps; ++j) { // outputs of step j - 1
             const unsigned char *T2r = T2 + ((j - 1) & 1) * BN56_T2_BYTES;
-            bn56_row mid = out;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mid.step(VH);
-            load_side(mid, s1, true);
-            half(T2r, 0, out, s0);
+            bn56_row r1 = out, r2, r3, r4;
+            r1.step(VH); r1.step(VH);
+            r2 = r1; r2.step(VH); r2.step(VH);
+            r3 = r2; r3.step(VH); r3.step(VH);
+            r4 = r3; r4.step(VH); r4.step(VH);
+            quarter(T2r, out, r1);
             bn56_barrier(); // E
-            bn56_row nxt = mid;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) nxt.step(VH);
-            load_side(nxt, s0, j < nsteps); // the next step's first half
+            BN56_STAMP(5); // wait at E
+            quarter(T2r + 2 * 2048, r1, r2);
             bn56_barrier(); // C
-            half(T2r, 1, mid, s1);
-            out = nxt;
+            BN56_STAMP(5); // wait at C
+            quarter(T2r + 4 * 2048, r2, r3);
+            quarter(T2r + 6 * 2048, r3, r4);
+            out = r4;
             if (j < nsteps) bn56_barrier(); // D (the front waves' last D belongs to step nsteps - 1; their two trailing barriers pair with this iteration's E, C)
+            BN56_STAMP(5); // wait at D
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BN56_TIMER_FLUSH(1);
     }
 }

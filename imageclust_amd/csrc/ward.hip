@@ -151,7 +151,6 @@ struct icl_ward_ws {
     size_t wxb_attr = 0;       // dynamic LDS the bound instantiation of the update kernel has been opted in for
     void *zero = nullptr;      // 256 zero bytes (LDS-DMA source of rows beyond n)
     int64_t dtri_floats = 0;
-    std::vector<std::pair<std::pair<int64_t, int64_t>, float *>> staged; // foreign distance rows [lo, hi) in transport (packed) format, unpacked by the next cluster call
     int32_t *merges = nullptr; // [2*N]
     ward_state *st = nullptr;
     // find_closest scratch
@@ -178,8 +177,6 @@ void icl_ward_free(icl_ctx *ctx)
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
                     w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mu, w->cand, w->rl_cnt, w->rl_col, w->rl_B};
-    for (auto &sp : w->staged)
-        if (sp.second) (void)hipFree(sp.second);
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -4020,9 +4017,6 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         w->zero = nullptr;
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
-        for (auto &sp : w->staged)
-            if (sp.second) (void)hipFree(sp.second);
-        w->staged.clear();
         if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
         w->graph_exec = nullptr;
         w->CT = w->Crow = w->cnew = w->cnewI = w->rowmin = w->Dtri = nullptr;
@@ -4303,8 +4297,8 @@ static int assign_ids(icl_ctx *ctx, int64_t n, int32_t min_size, int32_t max_siz
 }
 
 // own_lo / own_hi: rows of the initial distance matrix this call computes itself (whole 128-row tile rows; everything by
-// default).  The other rows must already sit in the triangle (icl_ward_deposit_dev): the multi-GPU paths compute them on
-// the other GPUs and send them here over xGMI.
+// default).  The other rows must already sit in the matrix (icl_ward_unpack_spans_dev): the multi-GPU paths compute them on
+// the other GPUs, and this GPU reads them over xGMI.
 static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                           int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters, int64_t own_lo = 0, int64_t own_hi = -1)
 {
@@ -4386,13 +4380,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                                       icl_ceil_div(own_hi, DT_TILE), ctx->stream));
     } else
         ICL_TRY(launch_dist_exact_rows(ctx, d_E, nullptr, n, d, w->Dtri, w->rowoff, 0, 0, own_lo / DT_TILE, icl_ceil_div(own_hi, DT_TILE)));
-    // rows computed elsewhere (other GPUs) arrived in the transport format -- spans of the packed lower triangle -- and are
-    // laid out into the matrix rows here
-    for (auto &sp : w->staged) {
-        const int64_t lo = sp.first.first, hi = std::min<int64_t>(sp.first.second, n);
-        if (hi <= lo) continue;
-        hipLaunchKernelGGL(ward_unpack_span_kernel, dim3((unsigned)std::min<int64_t>(hi - lo, 65535)), dim3(256), 0, ctx->stream, sp.second, lo, hi, w->Dtri, w->ld);
-    }
+    // (rows computed on other GPUs were laid out into the matrix by icl_ward_unpack_spans_dev before this call)
     {
         icl_prof_scope ps(ctx, ICL_K_ROWMIN, 0.0, 4.0 * (double)n * (double)(n - 1) * 0.5);
         wrefine rf_init = rf;
@@ -4602,9 +4590,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 
     ICL_HIP(ctx, hipMemcpyAsync(&hst, w->st, sizeof hst, hipMemcpyDeviceToHost, ctx->stream));
     ICL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &sp : w->staged)
-        if (sp.second) (void)hipFree(sp.second);
-    w->staged.clear();
     // The loop ends when len(clusters) == k or no mergeable pair is left (clustering.go:220-225).  Anything else -- the chunk
     // budget of the batched loop ran out, a replay did nothing -- is an engine failure, never a shorter clustering.
     if (!(hst.done || hst.t >= T))
@@ -4682,9 +4667,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 
 // ---- distance tiles over several GPUs ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI") ----------
 // A packed lower triangle stores its rows back to back, so a run of rows [lo, hi) is ONE contiguous span of floats: a GPU
-// computes the span of its own rows into a buffer of that size, the span travels as it is (peer copy / RCCL send: every byte
-// is a distance, nothing is padded to the matrix pitch) into a staging buffer of the clustering GPU, and the next cluster call
-// lays the staged spans out into the matrix rows (ward_unpack_span_kernel).  Rows are dealt in whole 128-row tile rows,
+// computes the span of its own rows into a buffer of that size and the span travels as it is (every byte is a distance, nothing
+// is padded to the matrix pitch): the clustering GPU reads it where it lies (peer access over xGMI) or receives it piecewise into a
+// bounded landing buffer (RCCL), and icl_ward_unpack_spans_dev lays it out into the matrix rows.  Rows are dealt in whole 128-row tile rows,
 // balanced by AREA (tile row ti has ti+1 tiles), not by row count.
 extern "C" int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi)
 {
@@ -4742,71 +4727,45 @@ extern "C" int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d)
     });
 }
 
-// Where rows [row_lo, row_hi) computed elsewhere are to be delivered on this GPU: a staging buffer in the transport format
-// (allocated on first request, owned by the context, consumed and released by the next icl_cluster_prefilled_dev).
-static int ward_stage_locked(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, float **out, int64_t *cnt)
+// Lays spans of the packed triangle that were computed elsewhere straight into the rows of this GPU's distance matrix.  d_spans[i]
+// must be READABLE from this GPU: its own memory (a landing buffer a transport has just filled), or another GPU's memory mapped
+// by hipDeviceEnablePeerAccess -- the reads then cross xGMI, and nothing is staged here: the clustering GPU holds the 4 n^2-byte
+// matrix and O(n d) beside it, whatever the number of parts.  One launch per span, each on a stream of its own (spans of several
+// peers cross their links concurrently); returns when every row is in place.  Call icl_ward_prepare(n, d) first; the rows this
+// GPU computes itself are the own_lo / own_hi of the following icl_cluster_prefilled_dev.
+extern "C" int icl_ward_unpack_spans_dev(icl_ctx *ctx, int32_t nspans, const int64_t *row_lo, const int64_t *row_hi, const float *const *d_spans)
 {
-    icl_ward_ws *w = ctx->ward;
-    if (!w || !w->Dtri || row_hi > w->capN) return icl_fail(ctx, ICL_ERR_ARG, "call icl_ward_prepare(n, d) before delivering distance rows");
-    *cnt = tri_rowoff(row_hi) - tri_rowoff(row_lo);
-    for (auto &sp : w->staged)
-        if (sp.first.first == row_lo && sp.first.second == row_hi) {
-            *out = sp.second;
-            return ICL_OK;
-        }
-    float *p = nullptr;
-    if (hipMalloc((void **)&p, (size_t)std::max<int64_t>(*cnt, 4) * 4) != hipSuccess)
-        return icl_fail(ctx, ICL_ERR_NOMEM, "staging buffer for distance rows [%lld, %lld): %lld floats", (long long)row_lo, (long long)row_hi, (long long)*cnt);
-    try {
-        w->staged.push_back({{row_lo, row_hi}, p});
-    } catch (...) {
-        (void)hipFree(p);
-        return icl_fail(ctx, ICL_ERR_NOMEM, "out of host memory");
-    }
-    *out = p;
-    return ICL_OK;
-}
-
-extern "C" int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt)
-{
-    if (!ctx || !d_ptr || !float_cnt || row_lo < 0 || row_hi < row_lo) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_span_ptr: bad argument");
+    if (!ctx || nspans < 0 || nspans > 1024 || (nspans && (!row_lo || !row_hi || !d_spans))) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_unpack_spans_dev: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
-    float *p = nullptr;
-    ICL_TRY(ward_stage_locked(ctx, row_lo, row_hi, &p, float_cnt));
-    *d_ptr = p;
+    icl_ward_ws *w = ctx->ward;
+    if (!w || !w->Dtri) return icl_fail(ctx, ICL_ERR_ARG, "call icl_ward_prepare(n, d) before delivering distance rows");
+    for (int i = 0; i < nspans; ++i)
+        if (row_lo[i] < 0 || row_hi[i] < row_lo[i] || row_hi[i] > w->capN || (row_hi[i] > row_lo[i] && !d_spans[i]))
+            return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_unpack_spans_dev: rows [%lld, %lld) outside the prepared matrix (n = %lld) or null span", (long long)row_lo[i],
+                            (long long)row_hi[i], (long long)w->capN);
+    hipError_t e = hipStreamSynchronize(ctx->stream); // the workspace is idle
+    hipStream_t cs[8] = {};
+    const int ns = std::min<int>(nspans, 8);
+    for (int i = 0; i < ns && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking);
+    for (int i = 0; i < nspans && e == hipSuccess; ++i) {
+        const int64_t lo = row_lo[i], hi = row_hi[i];
+        if (hi <= lo) continue;
+        hipLaunchKernelGGL(ward_unpack_span_kernel, dim3((unsigned)std::min<int64_t>(hi - lo, 65535)), dim3(256), 0, cs[i % ns], d_spans[i], lo, hi, w->Dtri, w->ld);
+        e = hipGetLastError();
+    }
+    for (int i = 0; i < ns; ++i)
+        if (cs[i]) {
+            const hipError_t e2 = hipStreamSynchronize(cs[i]);
+            if (e == hipSuccess) e = e2;
+            (void)hipStreamDestroy(cs[i]);
+        }
+    if (e != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "icl_ward_unpack_spans_dev: %s", hipGetErrorString(e));
     return ICL_OK;
 }
 
-// Copies a span computed elsewhere (this or another GPU: a peer copy over xGMI when the devices are peers) into the staging
-// buffer of its rows.  The context's mutex is held only while the buffer is looked up: the copy runs on a stream of its own, so
-// the spans of several GPUs arrive concurrently (one link each) while this GPU computes its own rows.
-extern "C" int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span)
-{
-    if (!ctx || row_lo < 0 || row_hi < row_lo) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_deposit_dev: bad argument");
-    float *dst = nullptr;
-    int64_t cnt = 0;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        icl_device_guard g(ctx->device);
-        ICL_TRY(ward_stage_locked(ctx, row_lo, row_hi, &dst, &cnt));
-    }
-    if (cnt == 0) return ICL_OK;
-    if (!d_span) return icl_fail(ctx, ICL_ERR_ARG, "icl_ward_deposit_dev: null span");
-    icl_device_guard g(ctx->device);
-    hipStream_t cs = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_span, (size_t)cnt * 4, hipMemcpyDefault, cs);
-    if (e == hipSuccess) e = hipStreamSynchronize(cs);
-    if (cs) (void)hipStreamDestroy(cs);
-    if (e != hipSuccess) {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        return icl_fail(ctx, ICL_ERR_HIP, "icl_ward_deposit_dev: copy of rows [%lld, %lld) failed: %s", (long long)row_lo, (long long)row_hi, hipGetErrorString(e));
-    }
-    return ICL_OK;
-}
-
-// icl_cluster_dev where the caller has already deposited every row of the initial distance matrix outside [own_lo, own_hi).
+// icl_cluster_dev where the caller has already laid every row of the initial distance matrix outside [own_lo, own_hi) into place
+// (icl_ward_unpack_spans_dev).
 extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                          int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
@@ -4816,7 +4775,7 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
     std::lock_guard<std::mutex> lk(ctx->mu);
     icl_device_guard g(ctx->device);
     if (!ctx->ward || ctx->ward->capN != n || ctx->ward->capD != d)
-        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: call icl_ward_prepare(n, d) and deposit the foreign rows first");
+        return icl_fail(ctx, ICL_ERR_ARG, "icl_cluster_prefilled_dev: call icl_ward_prepare(n, d) and icl_ward_unpack_spans_dev for the foreign rows first");
     return cluster_locked(ctx, d_E, n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters, own_lo, own_hi);
     });
 }

@@ -3,10 +3,12 @@ rendezvous and the one real exchange step of the path -- assembling E on every r
 
 * embed shards naturally: rank r owns the contiguous image range shard_range(n_total, r, world); no collective.
 * E is assembled with ONE all-gather (backend "nccl" == RCCL over xGMI on MI355X; "gloo" on CPU in the tests).
-* the initial distance matrix (clustering.go:61-73) is built on ALL ranks: rank r computes an area-balanced run of
-  128-row tile rows (one contiguous span of the packed triangle) and sends it to rank 0, which receives it straight into its
-  triangle ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI"); rank 0 computes its own run
-  meanwhile.  No data-path collective: 7 point-to-point sends, one per xGMI link into GPU 0.
+* the initial distance matrix (clustering.go:61-73) can be built on ALL ranks (cluster_with_distributed_tiles): rank r computes
+  an area-balanced run of 128-row tile rows (one contiguous span of the packed triangle) and sends it to rank 0 in pieces of
+  whole rows; rank 0 receives every piece into one of two bounded landing buffers per peer and lays it out into its distance
+  matrix at once (icl_ward_unpack_spans_dev), so it never holds more than the 4 n^2-byte matrix plus the landing buffers
+  ("tiles computed on 8 GPUs, scattered to GPU0 over xGMI"); its own run comes from the matrix-core bounds
+  inside the cluster call.  No data-path collective: 7 point-to-point streams, one per xGMI link into GPU 0.
 * the exact merge loop runs on rank 0 (BASELINE.json configs[2]: "tiled Ward distance on GPU0").
 
 Nothing here computes on tensors: device work stays in libimageclust_hip.so.
@@ -83,69 +85,88 @@ def tile_plan(n: int, world: int):
     return plan
 
 
-SPAN_CHUNK = 1 << 28  # floats per point-to-point message (1 GiB): a rank's span can exceed 2^31 elements (40 GB at world 2)
+SPAN_CHUNK = 1 << 26  # floats per point-to-point message (256 MiB): the size of a landing buffer on rank 0
 
 
-def exchange_spans(rank: int, world: int, plan, my_span, recv_buffer, chunk: int = 0):
-    """The one exchange of the distance build: every rank r > 0 sends its span to rank 0 in messages of at most `chunk`
-    floats (default SPAN_CHUNK).  On rank 0 recv_buffer(r) returns the tensor the span of rank r lands in (for the GPU path: a
-    view of the triangle itself).  Returns the pending requests (rank 0) so the caller can compute its own rows while the
-    transfers run; messages of one peer are matched in order, peers proceed concurrently (one xGMI link each)."""
-    if world <= 1:
-        return []
+def row_pieces(row_lo: int, row_hi: int, max_floats: int):
+    """Cuts the rows [row_lo, row_hi) into runs of WHOLE rows of at most max_floats floats each (at least one row per run):
+    [(r0, r1, float offset inside the span, floats)].  Sender and receiver derive the same cut."""
+    from . import _lib
+
+    base = _lib.ward_span(0, row_lo)[1]
+    out, r0 = [], row_lo
+    while r0 < row_hi:
+        # rows near r hold ~r floats: first guess by the row length, then adjust
+        r1 = min(row_hi, r0 + max(1, max_floats // max(r0 + 4, 4)))
+        while r1 < row_hi and _lib.ward_span(r0, r1 + 1)[1] <= max_floats:
+            r1 += 1
+        while r1 > r0 + 1 and _lib.ward_span(r0, r1)[1] > max_floats:
+            r1 -= 1
+        out.append((r0, r1, _lib.ward_span(0, r0)[1] - base, _lib.ward_span(r0, r1)[1]))
+        r0 = r1
+    return out
+
+
+def send_pieces(span: torch.Tensor, row_lo: int, row_hi: int, chunk: int = 0):
+    """Rank r > 0: its span (rows [row_lo, row_hi) of the packed triangle) to rank 0, one message per run of whole rows."""
+    for _, _, off, c in row_pieces(row_lo, row_hi, int(chunk) if chunk else SPAN_CHUNK):
+        dist.send(span[off:off + c], dst=0)
+
+
+def receive_pieces(plan, world: int, make_buffer, deliver, chunk: int = 0):
+    """Rank 0: receives every other rank's span piece by piece.  make_buffer(floats) allocates a landing buffer (two per peer, so
+    piece k + 1 of a peer is in flight while piece k is consumed); deliver(row_lo, row_hi, tensor) consumes a landed piece and
+    returns once the buffer may be overwritten.  Peers proceed concurrently (one xGMI link each), messages of one peer arrive in
+    order.  Rank 0 never holds more than 2 x (world - 1) landing buffers of at most `chunk` floats (or one row)."""
     chunk = int(chunk) if chunk else SPAN_CHUNK
-    if rank != 0:
-        cnt = plan[rank][3]
-        for off in range(0, cnt, chunk):
-            dist.send(my_span[off:min(off + chunk, cnt)], dst=0)
-        return []
-    reqs = []
-    bufs = {r: recv_buffer(r) for r in range(1, world) if plan[r][3] > 0}
-    nmsg = max((plan[r][3] + chunk - 1) // chunk for r in range(world))
-    for m in range(nmsg):  # round-robin over the peers so that every link has a receive posted from the start
-        for r, buf in bufs.items():
-            off = m * chunk
-            if off < plan[r][3]:
-                reqs.append(dist.irecv(buf[off:min(off + chunk, plan[r][3])], src=r))
-    return reqs
+    pieces = {r: row_pieces(plan[r][0], plan[r][1], chunk) for r in range(1, world) if plan[r][3] > 0}
+    land = {r: [make_buffer(max(c for _, _, _, c in p)) for _ in range(min(2, len(p)))] for r, p in pieces.items()}
+    pend = {r: [] for r in pieces}  # per peer: [(piece index, request)]
+    nxt = {r: 0 for r in pieces}
+
+    def post(r):
+        k = nxt[r]
+        if k < len(pieces[r]):
+            pend[r].append((k, dist.irecv(land[r][k % len(land[r])][:pieces[r][k][3]], src=r)))
+            nxt[r] = k + 1
+
+    for r in pieces:  # every link has receives posted from the start
+        for _ in land[r]:
+            post(r)
+    while any(pend.values()):
+        for r in pieces:  # round-robin over the peers
+            if not pend[r]:
+                continue
+            k, req = pend[r].pop(0)
+            req.wait()
+            r0, r1, _, c = pieces[r][k]
+            deliver(r0, r1, land[r][k % len(land[r])][:c])
+            post(r)
 
 
-def cluster_with_distributed_tiles(ctx, E_full: torch.Tensor, min_size: int, max_size: int, rank: int, world: int, update=0, staged=False):
+def cluster_with_distributed_tiles(ctx, E_full: torch.Tensor, min_size: int, max_size: int, rank: int, world: int, update=0, staged=False,
+                                   chunk: int = 0):
     """PerformClusteringWithConstraints over `world` GPUs: distance rows on every rank, merge loop on rank 0.
-    Returns (cluster_id, member_rank, n_clusters) on rank 0 and None elsewhere.  staged=True moves the spans through host
-    memory (gloo rehearsal on a box whose ranks share one GPU)."""
+    Returns (cluster_id, member_rank, n_clusters) on rank 0 and None elsewhere.  staged=True moves the pieces through host
+    memory (gloo rehearsal on a box whose ranks share one GPU).  chunk: floats per message (default SPAN_CHUNK)."""
     n, d = E_full.shape
     plan = tile_plan(n, world)
     lo, hi, _, cnt = plan[rank]
     if rank != 0:
-        span = torch.empty(max(cnt, 1), dtype=torch.float32, device=E_full.device)
         if cnt:
+            span = torch.empty(cnt, dtype=torch.float32, device=E_full.device)
             ctx.ward_distance_rows_dev(E_full.data_ptr(), n, d, lo, hi, span.data_ptr())
-        exchange_spans(rank, world, plan, span[:cnt].cpu() if staged else span[:cnt], None)
+            send_pieces(span.cpu() if staged else span, lo, hi, chunk)
         return None
     ctx.ward_prepare(n, d)
-    views = {}
 
-    def recv_buffer(r):
-        if staged:
-            views[r] = torch.empty(plan[r][3], dtype=torch.float32)
-        else:
-            ptr, c = ctx.ward_span_ptr(plan[r][0], plan[r][1])
-            views[r] = torch.as_tensor(_DeviceSpan(ptr, c), device=E_full.device)
-        return views[r]
+    def deliver(r0, r1, buf):
+        dev = buf.to(E_full.device) if staged else buf
+        torch.cuda.current_stream().synchronize()  # the transport's write into the landing buffer is complete
+        ctx.ward_unpack_spans_dev([(r0, r1, dev.data_ptr())])  # returns when the rows are in place
 
-    reqs = exchange_spans(rank, world, plan, None, recv_buffer)
-    if cnt:  # rank 0's own rows, written into its triangle while the other spans arrive
-        ptr, _ = ctx.ward_span_ptr(lo, hi)
-        ctx.ward_distance_rows_dev(E_full.data_ptr(), n, d, lo, hi, ptr)
-    for q in reqs:
-        q.wait()
-    if staged:
-        for r, t in views.items():
-            dev = t.to(E_full.device)
-            ctx.ward_deposit_dev(plan[r][0], plan[r][1], dev.data_ptr())
-    torch.cuda.synchronize()
-    return ctx.cluster_prefilled_dev(E_full.data_ptr(), n, d, min_size, max_size, 0, 0, update)
+    receive_pieces(plan, world, lambda c: torch.empty(c, dtype=torch.float32, device="cpu" if staged else E_full.device), deliver, chunk)
+    return ctx.cluster_prefilled_dev(E_full.data_ptr(), n, d, min_size, max_size, lo, hi, update)
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

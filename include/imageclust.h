@@ -124,10 +124,10 @@ int icl_bottleneck56(icl_ctx *ctx, const float *x, int B, int H, int W, int Cin,
 
 /* ---- several GPUs behind one handle ------------------------------------------------------------------
  * workflow.go:89,161 run in ONE process: a group drives ndev contexts from ndev host threads.  embed shards the images by
- * contiguous index ranges; cluster computes the initial distance rows (clustering.go:61-73) on every GPU in area-balanced
- * runs of 128-row tile rows, copies each span device-to-device into GPU 0 (staging memory, then laid out into its distance
- * matrix) and runs the exact merge loop on GPU 0.  Outputs are bit-identical to the single-GPU calls.  devices[] entries may
- * repeat (tests on a 1-GPU box). */
+ * contiguous index ranges; cluster builds the initial distance matrix (clustering.go:61-73) on GPU 0 alone (matrix-core bounds)
+ * or, from 6 GPUs on, on every GPU in area-balanced runs of 128-row tile rows that GPU 0 reads out of its peers' memory over
+ * xGMI straight into its matrix (icl_group_set_options), and runs the exact merge loop on GPU 0.  Outputs are bit-identical to
+ * the single-GPU calls.  devices[] entries may repeat (tests on a 1-GPU box). */
 typedef struct icl_group icl_group;
 int icl_group_create(const int32_t *devices, int32_t ndev, icl_group **out);
 void icl_group_destroy(icl_group *g);
@@ -148,17 +148,24 @@ int icl_group_cluster(icl_group *g, const float *E, int64_t n, int32_t d, int32_
 int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int prec, int32_t min_size, int32_t max_size, int update,
                             float *E_out, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 
+/* Who builds the initial distance matrix of a group (clustering.go:61-73): ICL_TILES_AUTO (default) lets GPU 0 build all of it
+ * from matrix-core bounds below 6 GPUs (one GPU fills the matrix faster than its peers' exact rows arrive over one xGMI link
+ * each) and deals the rows out from 6 GPUs on; ICL_TILES_LOCAL / ICL_TILES_DISTRIBUTED force either.  Results do not depend on it. */
+enum { ICL_TILES_AUTO = 0, ICL_TILES_LOCAL = 1, ICL_TILES_DISTRIBUTED = 2 };
+int icl_group_set_options(icl_group *g, int tiles_mode);
+
 /* The building blocks of the above, for callers that bring their own transport (bench.py: one process per GPU, RCCL
  * send/recv).  TRANSPORT FORMAT of distance rows: rows [row_lo, row_hi) of the packed lower triangle (row r = r floats, padded
- * to 4) are ONE contiguous span of floats.  The clustering GPU receives spans into staging buffers (icl_ward_span_ptr: a
- * transport writes there; icl_ward_deposit_dev: or has them copied) and lays them out into its distance matrix -- whose rows
- * and columns are recycled during the merge loop (4 n^2 bytes, ward.hip) -- at the next icl_cluster_prefilled_dev. */
+ * to 4) are ONE contiguous span of floats.  The clustering GPU lays spans it can READ -- a landing buffer of its own that a
+ * transport has just filled (any run of whole rows: bounded pieces), or a peer GPU's memory (hipDeviceEnablePeerAccess: the reads
+ * cross xGMI) -- straight into its distance matrix with icl_ward_unpack_spans_dev; nothing is staged, so the clustering GPU holds the
+ * matrix (4 n^2 bytes; rows and columns are recycled during the merge loop, ward.hip) plus O(n d) whatever the number of parts.
+ * The rows it computes itself are the own_lo / own_hi of icl_cluster_prefilled_dev (matrix-core bounds, as in icl_cluster_dev). */
 int icl_ward_rows_partition(int64_t n, int32_t parts, int32_t part, int64_t *row_lo, int64_t *row_hi); /* area-balanced, whole 128-row tile rows */
 int icl_ward_span(int64_t row_lo, int64_t row_hi, int64_t *float_off, int64_t *float_cnt);             /* where that span sits / how long it is */
 int icl_ward_distance_rows_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int64_t row_lo, int64_t row_hi, float *d_span);
 int icl_ward_prepare(icl_ctx *ctx, int64_t n, int32_t d);                                              /* allocate the clustering workspace */
-int icl_ward_span_ptr(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, void **d_ptr, int64_t *float_cnt);  /* staging buffer of those rows: receive foreign spans here */
-int icl_ward_deposit_dev(icl_ctx *ctx, int64_t row_lo, int64_t row_hi, const float *d_span);           /* ... or copy them in */
+int icl_ward_unpack_spans_dev(icl_ctx *ctx, int32_t nspans, const int64_t *row_lo, const int64_t *row_hi, const float *const *d_spans); /* spans -> matrix rows */
 int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                               int64_t own_lo, int64_t own_hi, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 

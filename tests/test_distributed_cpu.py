@@ -64,7 +64,7 @@ def test_shard_ranges_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-# ---- distance tiles over ranks (imageclust_amd/distributed.py: tile_plan / exchange_spans) ---------------------------
+# ---- distance tiles over ranks (imageclust_amd/distributed.py: tile_plan / row_pieces / send_pieces / receive_pieces) ----
 def _pack_rows(D, lo, hi):
     """Rows [lo, hi) of a dense matrix in the engine's packed-triangle layout: row r holds D[r, :r], padded to 4 floats."""
     out = []
@@ -109,21 +109,34 @@ def _span_worker(rank, world, port, n, q, chunk=0):
     assert mine.numel() == cnt
     ok = True
     if rank == 0:
+        from imageclust_amd import _lib
+
         tri = torch.zeros(sum(p[3] for p in plan), dtype=torch.float32)
         tri[off:off + cnt] = mine
-        reqs = D.exchange_spans(rank, world, plan, None, lambda r: tri[plan[r][2]:plan[r][2] + plan[r][3]], chunk)
-        for rq in reqs:
-            rq.wait()
-        ok = bool(torch.equal(tri, torch.from_numpy(_pack_rows(full, 0, n))))  # rank 0 now holds exactly the packed triangle
+        landed = []  # landing buffers handed out: at most two per peer, each at most one piece long
+
+        def make_buffer(c):
+            landed.append(c)
+            return torch.empty(c, dtype=torch.float32)
+
+        def deliver(r0, r1, buf):  # stands in for icl_ward_unpack_spans_dev: whole rows, at their place in the triangle
+            o, c = _lib.ward_span(0, r0)[1], _lib.ward_span(r0, r1)[1]
+            assert buf.numel() == c
+            tri[o:o + c] = buf
+
+        D.receive_pieces(plan, world, make_buffer, deliver, chunk)
+        ok = bool(torch.equal(tri, torch.from_numpy(_pack_rows(full, 0, n))))  # rank 0 has seen exactly the packed triangle
+        ok = ok and len(landed) <= 2 * (world - 1) and (not chunk or max(landed) <= max(chunk, (n + 3) // 4 * 4))
     else:
-        D.exchange_spans(rank, world, plan, mine, None, chunk)
+        if cnt:
+            D.send_pieces(mine, lo, hi, chunk)
     D.barrier()
     q.put((rank, ok))
     torch.distributed.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n,chunk", [(2, 300, 0), (3, 700, 0), (2, 129, 0), (3, 700, 4099), (2, 300, 1)])
-def test_span_exchange_assembles_the_packed_triangle_gloo(world, n, chunk):  # chunk > 0: spans cut into several messages
+def test_span_exchange_assembles_the_packed_triangle_gloo(world, n, chunk):  # chunk > 0: spans cut into several runs of whole rows
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

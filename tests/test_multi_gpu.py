@@ -1,5 +1,6 @@
 """Several GPUs behind the C-ABI (include/imageclust.h: icl_group_*, icl_ward_*span*): the group path and the
-process-per-GPU building blocks must reproduce the single-GPU results bit for bit.  The box has ONE GPU, so the groups
+process-per-GPU building blocks must reproduce the single-GPU results bit for bit, and the clustering GPU must hold
+nothing but its distance matrix and O(n d) beside it.  The box has ONE GPU, so the groups
 here hold several contexts on device 0 (icl_group_create allows repeated devices for exactly this) and the 2-process
 test shares the GPU and stages spans through host memory (gloo); the peer-copy / RCCL transports differ only in the copy."""
 import os
@@ -34,11 +35,15 @@ def test_group_embed_and_cluster_equal_single_gpu(L):
         assert np.array_equal(g.embed_u8(imgs, L.HEAD_POOLED, L.PREC_FP32), want32)
         assert np.array_equal(g.embed_u8(imgs, L.HEAD_DENSE0, L.PREC_BF16), want16)
         for (E, mn, mx) in [(WC.mog(1500, 32, 3), 5, 50), (WC.ties(1100, 4, 2, levels=5), 2, 9), (WC.mog(900, 2048, 4), 3, 6)]:
-            cid, rank, nc = g.cluster(E, mn, mx)
             c1, r1, n1 = ctx.cluster(E, mn, mx)
-            assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1)
             f = O.cluster_fast(E, mn, mx, lazy_ban=False)
-            assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"])
+            # auto (3 contexts: GPU 0 builds the matrix alone), and the rows dealt out over the three contexts
+            for mode in (L.TILES_AUTO, L.TILES_DISTRIBUTED, L.TILES_LOCAL):
+                g.set_options(mode)
+                cid, rank, nc = g.cluster(E, mn, mx)
+                assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1), mode
+                assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"]), mode
+        g.set_options(L.TILES_AUTO)
         # inputs too small to deal out, constraint errors and FAST mode take the single-GPU path with the same contract
         cid, rank, nc = g.cluster(WC.mog(64, 8, 1), 3, 6)
         r = O.cluster(WC.mog(64, 8, 1), 3, 6)
@@ -64,9 +69,11 @@ def test_group_embed_cluster_keeps_embeddings_on_the_gpus(L):
             imgs = L.synth_images(20250217, 11, n, L.SYNTH_STRUCTURED)
             want = ctx.embed_u8(imgs, L.HEAD_POOLED, L.PREC_BF16)
             c1, r1, n1 = ctx.cluster(want, mn, mx)
-            E, cid, rank, nc = g.embed_cluster(imgs, mn, mx, L.PREC_BF16)
-            assert np.array_equal(E.view(np.uint32), want.view(np.uint32))
-            assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1)
+            for mode in (L.TILES_DISTRIBUTED, L.TILES_AUTO):  # E on every GPU + rows dealt out / shards to GPU 0, which builds the matrix
+                g.set_options(mode)
+                E, cid, rank, nc = g.embed_cluster(imgs, mn, mx, L.PREC_BF16)
+                assert np.array_equal(E.view(np.uint32), want.view(np.uint32)), mode
+                assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1), mode
         _, cid, rank, nc = g.embed_cluster(imgs, 3, 6, L.PREC_BF16, want_E=False)
         assert nc == n1 and np.array_equal(cid, c1)
         with pytest.raises(L.ICLError) as ei:
@@ -100,18 +107,30 @@ def test_distance_row_spans_are_the_rows_of_the_matrix(L):
             for r in range(n):
                 assert np.array_equal(tri[pos:pos + r].view(np.uint32), full[r, :r].view(np.uint32)), (parts, r)
                 pos += (r + 3) // 4 * 4
-        # engine-owned triangle memory addressed from torch without a copy (what an RCCL recv writes into)
+        # spans laid straight into the distance matrix (icl_ward_unpack_spans_dev) + the clustering GPU's own rows inside the call
+        # (icl_cluster_prefilled_dev): every split of the rows between "computed elsewhere" and "own" gives the ids of the plain call
         from imageclust_amd import distributed as D
 
-        ctx.ward_prepare(n, d)
-        ptr, cnt = ctx.ward_span_ptr(128, 384)
-        t = torch.as_tensor(D._DeviceSpan(ptr, cnt), device="cuda")
-        assert t.numel() == cnt == L.ward_span(128, 384)[1] and t.data_ptr() == ptr
-        t.fill_(3.5)
-        torch.cuda.synchronize()
-        back = np.zeros(4, np.float32)
-        ctx.d2h(back, ptr + (cnt - 4) * 4)
-        assert (back == 3.5).all()
+        c1, r1, n1 = ctx.cluster(E, 5, 50)
+        for own in [(0, 0), (0, 256), (256, 700), (0, 700)]:
+            ctx.ward_prepare(n, d)
+            keep, spans = [], []
+            for lo, hi in [(0, own[0]), (own[1], n)]:
+                for (r0, r1_, _, c) in D.row_pieces(lo, hi, 5000) if hi > lo else []:  # several pieces of whole rows, as a transport delivers them
+                    a0 = r0 // 128 * 128  # distance rows come in whole 128-row tile rows: cut the piece out of its tile rows' span
+                    a1 = min(n, (r1_ + 127) // 128 * 128)
+                    buf = torch.full((max(L.ward_span(a0, a1)[1], 1),), -1.0, device="cuda")
+                    ctx.ward_distance_rows_dev(dE.data_ptr(), n, d, a0, a1, buf.data_ptr())
+                    piece = buf[L.ward_span(a0, r0)[1]:L.ward_span(a0, r0)[1] + c].clone()
+                    keep.append(piece)
+                    spans.append((r0, r1_, piece.data_ptr()))
+            torch.cuda.synchronize()
+            for i in range(0, len(spans), 3):
+                ctx.ward_unpack_spans_dev(spans[i:i + 3])
+            cid, rank, nc = ctx.cluster_prefilled_dev(dE.data_ptr(), n, d, 5, 50, own[0], own[1])
+            assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1), own
+        with pytest.raises(L.ICLError):  # rows outside the prepared matrix
+            ctx.ward_unpack_spans_dev([(0, n + 1, dE.data_ptr())])
     finally:
         ctx.close()
 
@@ -164,3 +183,56 @@ def test_two_ranks_distributed_tiles_equal_single_gpu():
         p.join(120)
         assert p.exitcode == 0
     assert res[0] is True
+
+
+def test_group_keeps_only_the_matrix_on_gpu0(L):
+    """Memory plan of the distributed distance build: GPU 0 holds the 4 n^2-byte matrix + O(n d); the foreign spans
+    stay in their owners' memory and are read over xGMI.  On this box the three contexts share ONE device, so the device-wide
+    peak (hipMemGetInfo, sampled while the call runs) is matrix + the two foreign spans (2 n^2 x 2/3 of the area) + three copies
+    of E -- the 2 n^2 bytes of staging that rounds 2-3 put on GPU 0 on top of that (every part's span, its own included) would
+    push it over the bound asserted here.  Results stay bit-identical to one GPU and to the oracle."""
+    import threading
+    import time
+
+    import torch
+
+    n, d = 30000, 64
+    E = WC.mog(n, d, 5)
+    ctx = L.Context(0)
+    g = L.Group([0, 0, 0])
+    try:
+        c1, r1, n1 = ctx.cluster(E, 5, 50)
+        ctx.close()  # its workspace (a second matrix) must not sit in the measurement
+        ctx = None
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        low = [free0]
+        stop = threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                low[0] = min(low[0], torch.cuda.mem_get_info()[0])
+                time.sleep(0.002)
+
+        th = threading.Thread(target=poll)
+        th.start()
+        try:
+            g.set_options(L.TILES_DISTRIBUTED)
+            cid, rank, nc = g.cluster(E, 5, 50)
+        finally:
+            stop.set()
+            th.join()
+        assert nc == n1 and np.array_equal(cid, c1) and np.array_equal(rank, r1)
+        peak = free0 - low[0]
+        matrix = 4 * (n + 16) * ((n + 63) // 64 * 64)
+        spans = 4 * sum(L.ward_span(*L.ward_rows_partition(n, 3, p))[1] for p in (1, 2))
+        slack = 3 * n * d * 4 * 3 + (256 << 20)  # E (three contexts), centroid copies, tables, allocator granularity
+        print("device-wide peak %.2f GB; matrix %.2f GB + foreign spans %.2f GB" % (peak / 1e9, matrix / 1e9, spans / 1e9))
+        assert peak <= matrix + spans + slack, (peak, matrix, spans)
+        assert peak >= matrix  # the poller really saw the run
+    finally:
+        g.close()
+        if ctx is not None:
+            ctx.close()
+    f = O.cluster_fast(E, 5, 50, lazy_ban=False)
+    assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"])
