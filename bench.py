@@ -37,13 +37,15 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 3857973248  # 53 conv + 1 fc, MACs x 2
 
 
-def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s=75.0):
+def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s=75.0, ctx=None):
     """The CPU restatement of the reference algorithm (oracle/, kind "port"), timed on this box's host cores as SURVEY.md
     8d prescribes: (i) embed = the fp32 ResNet50 restatement, batch 1, serial calls, all cores inside a call (OpenCV-DNN is
     internally multi-threaded, embeddings.go:133-141), 64 images; (ii) Ward = the literal O(N^3) restatement, ONE thread
     (the reference clusters on one goroutine, workflow.go:89), at N in {64, 1000, 2000, 4000}, D=2048, (min,max) = (3,6)
     for N=64 (handlers.go:111) and (5,50) otherwise, with the fitted a*N^3 + b*N^2*D model.  Nothing is extrapolated to
-    100k: `value` is the measured rate of the largest measured job (embed N images + cluster them)."""
+    100k: `value` is the measured rate of the largest measured job (embed N images + cluster them).
+    With ctx (the engine's context) the same inputs also go through the GPU path and the second return value is the `parity`
+    object of the JSON line: the oracle is the checker here, never the thing measured."""
     from oracle import oracle as O
     from imageclust_amd import _lib
 
@@ -63,6 +65,12 @@ def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s
             break
     t_embed = time.perf_counter() - t0
     embed_rate = done / t_embed
+    parity = None
+    if ctx is not None:  # the parity path (fp32) on 4 of the images the oracle has just embedded, against the oracle's embeddings
+        ref4 = np.stack([O.resnet50_forward(blob, imgs[i])[0] for i in range(4)])
+        got4 = ctx.embed_u8(imgs[:4], _lib.HEAD_POOLED, _lib.PREC_FP32)
+        parity = {"embed_fp32_max_rel_err": float("%.3g" % (np.abs(got4 - ref4).max() / max(1.0, float(np.abs(ref4).max())))),
+                  "embed_fp32_tolerance": 1e-4, "embed_images_compared": 4}
     rng = np.random.default_rng(20250217)
     ward = []
     for n_ward in ward_sizes:
@@ -72,14 +80,19 @@ def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s
         E = (cen[rng.integers(0, len(cen), n_ward)] + 0.1 * rng.standard_normal((n_ward, d))).astype(np.float32)
         mn, mx = (3, 6) if n_ward == 64 else (5, 50)
         t0 = time.perf_counter()
-        O.cluster(E, mn, mx, threads=1)
+        ref = O.cluster(E, mn, mx, want_log=True, threads=1)
         ward.append((n_ward, time.perf_counter() - t0))
+        if ctx is not None:  # the same E through the engine: ids, member order and the merge sequence, bit for bit
+            cid, mr, nc = ctx.cluster(E, mn, mx)
+            same = bool(nc == ref["n_clusters"] and np.array_equal(cid, ref["cluster_id"]) and np.array_equal(mr, ref["member_rank"])
+                        and np.array_equal(ctx.last_merges(), ref["log"][:, 2:4].astype(np.int32)))
+            parity["ward_ids_and_log_equal_n%d" % n_ward] = same
     # least squares for t = a*N^3 + b*N^2*D (the scan and the distance/row-refresh terms of SURVEY.md 3.3)
     A = np.array([[float(n) ** 3, float(n) ** 2 * d] for n, _ in ward])
     coef, *_ = np.linalg.lstsq(A, np.array([t for _, t in ward]), rcond=None)
     n_big, t_big = ward[-1]
     value = n_big / (n_big / embed_rate + t_big)
-    return {"value": round(value, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+    base = {"value": round(value, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "oracle/ CPU restatement: embed %d images (batch 1, serial calls, OpenMP %d threads: %.2f img/s) + Ward D=%d on 1 "
                       "thread at N=%s (%s s); value = the measured N=%d job: %d/(%d/embed_rate + %.2f s); no size beyond "
                       "N=%d is measured or extrapolated" % (done, cores, embed_rate, d, [n for n, _ in ward],
@@ -88,27 +101,31 @@ def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s
             "ward_seconds": {str(n): round(t, 3) for n, t in ward},
             "ward_fit": {"model": "t = a*N^3 + b*N^2*D seconds", "a": float("%.4g" % coef[0]), "b": float("%.4g" % coef[1])},
             "seconds_total": round(time.perf_counter() - t_start, 1)}
+    return base, parity
 
 
 def layerwise_roofline_seconds(batch):
-    """Sum over the ResNet50-v1 launches of max(flops / bf16 MFMA peak, HBM bytes / HBM peak) for one batch: the time the
-    forward pass would take if every layer sat on its own roofline (activations bf16 NHWC, each tensor read and written
-    once per launch, residual read once, downsample branch fused).  Context for the per-kernel roofline fraction: most
-    1x1 layers are HBM-side, the 3x3 layers MFMA-side."""
+    """Sum over the launches of the ResNet50-v1 forward pass of max(flops / bf16 MFMA peak, HBM bytes / HBM peak) for one batch:
+    the time the pass would take if every launch sat on its own roofline (activations bf16 NHWC, each tensor read and written once
+    per launch, residual read once, downsample branch fused; since round 4 the stem + maxpool and each stage-1 bottleneck are ONE
+    launch: image in / pooled tensor out, block input in / block output out).  Context for the per-kernel roofline fraction."""
     B = batch
-    lay = [(2 * B * 112 * 112 * 64 * 147, B * 224 * 224 * 3 + B * 112 * 112 * 64 * 2), (0, B * 112 * 112 * 64 * 2 + B * 56 * 56 * 64 * 2)]
+    lay = [(2 * B * 112 * 112 * 64 * 147, B * 224 * 224 * 3 + B * 56 * 56 * 64 * 2)]
     h, cin = 56, 64
     for s, nb in enumerate([3, 4, 6, 3]):
         cout = 256 << s
         mid = cout // 4
         for bl in range(nb):
             ho = h // (2 if (bl == 0 and s > 0) else 1)
-            lay.append((2 * B * ho * ho * mid * cin, (B * h * h * cin + B * ho * ho * mid) * 2))
-            lay.append((2 * B * ho * ho * mid * mid * 9, B * ho * ho * mid * 2 * 2))
-            if bl == 0:
-                lay.append((2 * B * ho * ho * cout * (mid + cin), (B * ho * ho * mid + B * h * h * cin + B * ho * ho * cout) * 2))
+            if s == 0:  # the whole bottleneck in one launch
+                lay.append((2 * B * ho * ho * (mid * cin + mid * mid * 9 + cout * (mid + (cin if bl == 0 else 0))), (B * h * h * cin + B * ho * ho * cout) * 2))
             else:
-                lay.append((2 * B * ho * ho * cout * mid, (B * ho * ho * mid + 2 * B * ho * ho * cout) * 2))
+                lay.append((2 * B * ho * ho * mid * cin, (B * h * h * cin + B * ho * ho * mid) * 2))
+                lay.append((2 * B * ho * ho * mid * mid * 9, B * ho * ho * mid * 2 * 2))
+                if bl == 0:
+                    lay.append((2 * B * ho * ho * cout * (mid + cin), (B * ho * ho * mid + B * h * h * cin + B * ho * ho * cout) * 2))
+                else:
+                    lay.append((2 * B * ho * ho * cout * mid, (B * ho * ho * mid + 2 * B * ho * ho * cout) * 2))
             cin, h = cout, ho
     lay.append((0, B * 49 * 2048 * 2))
     return sum(max(f / (PEAK_BF16_TFLOPS * 1e12), b / (PEAK_HBM_GBS * 1e9)) for f, b in lay)
@@ -143,10 +160,10 @@ def main():
                          "rank 0 fills the whole matrix itself with the matrix-core bounds (0.19 s at 100 000 images, nothing to transport); "
                          "auto = local: 0.49 s / N of exact arithmetic + the transport only beat 0.19 s from about 6 ranks on (estimated "
                          "0.12 s at 8), and the local build needs no point-to-point traffic at all")
-    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound", "bound-init"], default="auto",
+    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound"], default="auto",
                     help="exact mode only (include/imageclust.h ICL_DIST_*): how distances are produced -- every value on the vector ALUs, "
-                         "or proven lower bounds from the matrix cores with exact evaluation on demand (same ids, bit for bit); "
-                         "bound-init keeps UpdateDistanceMatrix's new rows on the exact kernel; auto: bounds for n >= 4096")
+                         "or proven lower bounds from the matrix cores in the initial matrix with exact evaluation on demand (same ids, bit for "
+                         "bit; UpdateDistanceMatrix's new rows are always exact values); auto: bounds for n >= 4096")
     ap.add_argument("--update", choices=["exact", "lw"], default="exact",
                     help="exact: centroid recompute, cluster ids bit-identical to the reference (default); "
                          "lw: MFMA distance tile + Lance-Williams rows (fast, not bit-identical)")
@@ -179,7 +196,7 @@ def main():
     from imageclust_amd import distributed as D
 
     ctx = _lib.Context(local_rank)
-    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2, "bound-init": 3}[args.ward_dist])
+    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2}[args.ward_dist])
     ctx.load_synthetic(1)
     ctx.set_batch(args.batch)
     if args.scaling == "weak":
@@ -322,7 +339,7 @@ def main():
                 break
             except Exception:
                 continue
-        conv_roof = {"bound": "mfma", "kernel": "conv kernels with Cout >= 128 (conv_igemm_kernel<%s,128>, conv3x3_halo_kernel<%s,128>)" % ((args.prec.upper().replace("FP32", "F32"),) * 2),
+        conv_roof = {"bound": "mfma", "kernel": "conv kernels with Cout >= 128 (conv_igemm_kernel<%s,128>, conv3x3_halo_kernel<%s,128>%s)" % ((args.prec.upper().replace("FP32", "F32"),) * 2 + (", bneck56_kernel: the fused stage-1 bottlenecks" if args.prec == "bf16" else "",)),
                      "achieved": round(achieved, 2),
                      "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(achieved / peak_mfma, 4), "traffic": traffic,
                      "launches": c128["launches"], "avg_launch_us": round(avg_us, 2),
@@ -336,12 +353,12 @@ def main():
         if upd and upd["launches"]:
             ws = ctx.last_ward_stats()
             gbs = upd["bytes"] / max(upd["ms"], 1e-9) / 1e6  # GB/s
-            exact = args.update == "exact" and args.ward_dist != "bound"  # (--ward-dist bound: the rows come from the matrix cores, the kernel streams: the HBM view)
+            exact = args.update == "exact"
             tfl = upd["flops"] / max(upd["ms"], 1e-9) / 1e9  # 3 flop per (pair, k): sub, mul, add -- unfused by construction
             # What binds the exact update is the vector ALU (16 rows x 3 unfused fp32 ops per byte-quad: 12 flop/B), not HBM:
             # `bound` says so, achieved / peak / frac are the vector-fp32 figures, the HBM view sits beside them in `hbm`.
             # (The Lance-Williams update of --update lw reads 12 bytes per pair: that one IS an HBM kernel.)
-            ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch2_kernel<true> + ward_newrow_min_kernel" if args.update == "exact" else "ward_update_batch_lw_kernel",
+            ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch_lw_kernel",
                          "achieved": round(tfl, 2) if exact else round(gbs, 1), "peak": PEAK_F32_TFLOPS if exact else PEAK_HBM_GBS,
                          "unit": "TFLOP/s" if exact else "GB/s",
                          "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
@@ -403,7 +420,15 @@ def main():
             ("roofline_conv" if ward_dominates else "roofline_ward_update"): (conv_roof if ward_dominates else ward_roof),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], par = cpu_baseline(ctx=ctx)
+            # the throughput of the parity precision itself: one untimed 10 000-image pass of the fp32 (f32 MFMA) forward
+            n10 = min(n_local, 10000)
+            ctx.embed_u8_dev(imgs.data_ptr(), n10, E_local.data_ptr(), DIM, _lib.PREC_FP32)
+            par["embed_fp32_img_per_s_10k"] = round(n10 / max(ctx.last_stage_ms()["embed_ms"], 1e-9) * 1e3, 1)
+            par["note"] = ("checked in this run against oracle/ (CPU restatement of clustering.go / the ONNX graph): cluster ids, member order and the merge "
+                           "sequence of the exact Ward path on the cpu_baseline inputs; the fp32 embedding path on 4 images (tolerance 1e-4 of the "
+                           "output scale).  The timed steps above run the bf16 embedding (configs[1]) and the same exact Ward path.")
+            out["parity"] = par
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,6 +18,7 @@ PREC_FP32, PREC_BF16 = 0, 1
 UPDATE_EXACT, UPDATE_LW = 0, 1
 SYNTH_NOISE, SYNTH_STRUCTURED = 0, 1
 TILES_AUTO, TILES_LOCAL, TILES_DISTRIBUTED = 0, 1, 2
+FILE_FAIL_NEXT_LEADER = 0x100
 K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER, K_CONV64 = range(7)
 K_NAMES = ["conv_igemm_kernel<*,128>", "ward_dist_exact_kernel", "dist_mfma_kernel", "row_argmin_*_kernel",
            "ward_update_exact_kernel", "embed_other", "conv_igemm_kernel<*,64>"]

@@ -1881,6 +1881,7 @@ struct icl_file_batcher {
     int prec = ICL_PREC_FP32;
     int window_us = 2000;
     int max_batch = 256;
+    bool fail_next = false; // ICL_FILE_FAIL_NEXT_LEADER: the next batch leader gives up right after taking its requests
     int64_t batches = 0, images = 0; // statistics (icl_file_batch_stats)
 };
 static icl_file_batcher *file_batcher(icl_ctx *ctx)
@@ -1898,10 +1899,13 @@ void icl_file_batcher_free(icl_ctx *ctx)
 
 extern "C" int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch)
 {
+    const bool fail_next = (prec & ICL_FILE_FAIL_NEXT_LEADER) != 0;
+    prec &= ~ICL_FILE_FAIL_NEXT_LEADER;
     if (!ctx || (prec != ICL_PREC_FP32 && prec != ICL_PREC_BF16) || window_us < 0 || max_batch < 1 || max_batch > 4096)
         return icl_fail(ctx, ICL_ERR_ARG, "icl_set_file_options: bad argument");
     icl_file_batcher *b = file_batcher(ctx);
     std::lock_guard<std::mutex> lk(b->m);
+    b->fail_next = fail_next;
     b->prec = prec;
     b->window_us = window_us;
     b->max_batch = max_batch;
@@ -1986,8 +1990,10 @@ extern "C" int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *o
                     take.resize((size_t)b->max_batch);
                 }
                 const int prec = b->prec;
+                const bool give_up = b->fail_next; // icl_set_file_options(ICL_FILE_FAIL_NEXT_LEADER): one leader fails as if out of memory
+                b->fail_next = false;
                 lk.unlock();
-                if (getenv("ICL_TEST_LEADER_THROW")) throw std::bad_alloc(); // fault injection for tests/test_pipeline_gpu.py
+                if (give_up) throw std::bad_alloc();
                 for (int hd : {ICL_HEAD_POOLED, ICL_HEAD_DENSE0}) { // one forward pass per requested head
                     std::vector<icl_file_req *> grp;
                     for (icl_file_req *r : take)

@@ -423,14 +423,14 @@ __global__ __launch_bounds__(256) void stem2_pool_kernel(const uint8_t *__restri
             if (m == 7) *reinterpret_cast<uint2 *>(carry_nxt + toff) = o;
         }
         __syncthreads(); // the pool tile is complete
-        // ---- maxpool 3x3/2 p1 (padding never wins): pooled rows 4t .. 4t+3, pooled columns 7s .. 7s+6; one 16-byte chunk per thread
+        // ---- maxpool 3x3/2 p1: pooled rows 4t .. 4t+3, pooled columns 7s .. 7s+6; one 16-byte chunk per thread.  Every value in the
+        // tile is a ReLU output, i.e. a non-negative bf16, whose bit pattern orders like a signed 16-bit integer: the maximum is
+        // taken on the packed halves (v_pk_max_i16), and 0 stands for the padding, which never wins
         if (tid < 28 * 8) {
             const int s = unit & 7;
             const int64_t b = unit >> 3;
             const int ch = tid & 7, pix = tid >> 3, pr = pix / 7, pc = pix - 7 * pr;
-            float best[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+            i16x2_t best[4] = {i16x2_t{0, 0}, i16x2_t{0, 0}, i16x2_t{0, 0}, i16x2_t{0, 0}};
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int rr = 2 * pr + kh; // 0: the carried conv row 8t-1; 1 .. 8: this tile's rows
@@ -441,18 +441,15 @@ __global__ __launch_bounds__(256) void stem2_pool_kernel(const uint8_t *__restri
                     const int ci = 2 * pc + kw; // conv column 14s - 1 + ci
                     if (s == 0 && ci == 0) continue;
                     const uint4 rawv = *reinterpret_cast<const uint4 *>(rowp + ci * 128 + (((ch ^ (ci >> 1)) & 7) << 4));
-                    const uint16_t *pvv = reinterpret_cast<const uint16_t *>(&rawv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = BF16::to_f(pvv[e]);
-                        if (f > best[e]) best[e] = f;
-                    }
+                    best[0] = __builtin_elementwise_max(best[0], __builtin_bit_cast(i16x2_t, rawv.x));
+                    best[1] = __builtin_elementwise_max(best[1], __builtin_bit_cast(i16x2_t, rawv.y));
+                    best[2] = __builtin_elementwise_max(best[2], __builtin_bit_cast(i16x2_t, rawv.z));
+                    best[3] = __builtin_elementwise_max(best[3], __builtin_bit_cast(i16x2_t, rawv.w));
                 }
             }
-            uint16_t o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = BF16::from_f(best[e]);
-            *reinterpret_cast<uint4 *>(Yg + ((b * 56 + 4 * t + pr) * 56 + 7 * s + pc) * 64 + ch * 8) = *reinterpret_cast<const uint4 *>(o);
+            const uint4 o = make_uint4(__builtin_bit_cast(uint32_t, best[0]), __builtin_bit_cast(uint32_t, best[1]), __builtin_bit_cast(uint32_t, best[2]),
+                                       __builtin_bit_cast(uint32_t, best[3]));
+            *reinterpret_cast<uint4 *>(Yg + ((b * 56 + 4 * t + pr) * 56 + 7 * s + pc) * 64 + ch * 8) = o;
         }
         if (!has_next) break;
         unit = nu;

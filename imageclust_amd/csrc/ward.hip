@@ -31,9 +31,9 @@
 // bound of the reference's value, not a value (distance_mfma.hip derives it).  From n = 4096 the initial matrix is filled with
 // such bounds by a GEMM on the matrix cores; the row scans (scan_row_min) evaluate an entry exactly -- the reference's own
 // sequential expression, ward_sqdist_wave -- only when its bound reaches the row's minimum, so nothing a comparison sees is
-// ever a bound.  On request (ICL_DIST_BOUND) the update kernel's main workgroups write the rows of the clusters being created
-// as bounds too (wx_main_bound: v_mfma_f32_16x16x4_f32), ward_newrow_min_kernel finds their exact minima from per-row
-// candidate lists and leaves each row a nearest-neighbour list; measured slower end to end than the exact rows.
+// ever a bound.  (Round 3 also wrote the rows of the clusters being CREATED as bounds -- a second body of the update kernel,
+// exact minima by a kernel of its own, nearest-neighbour lists: parity-green, slower end to end at every size measured
+// (N = 100 000: 3 264 against 2 984 ms per step), retired in round 4; DESIGN.md 3 keeps the numbers.)
 #pragma clang fp contract(off)
 
 #include "icl_common.h"
@@ -92,13 +92,10 @@ struct ward_batch_state {
     unsigned long long sum_dep;                   // sum over steps of rows whose cached partner is a member of the batch
     unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
     unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
-    // bound body of the update kernel: per new row, the smallest UPPER bound seen so far among the clusters that survive the batch
-    // (float bits; only ever lowered) and the number of columns appended to the row's candidate list (entries whose lower bound did
-    // not exceed that threshold when they were written + every valid entry of a later pick's member)
-    unsigned int ub2[WB_K];
-    int32_t cand_n[WB_K];
-    unsigned long long dbg[8], dbg_t0, dbg2[3], dbg3[4], dbg4[4], dbg5[4], dbg6[8];
-    unsigned long long rf_stat[12];  // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
+#ifdef ICL_WARD_TIMERS
+    unsigned long long dbg[8], dbg_t0, dbg2[3], dbg3[4], dbg4[4], dbg5[4], dbg6[8]; // in-kernel stage timers
+    unsigned long long rf_stat[8];   // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
+#endif
     int32_t blk_next, blk_pad;       // the persistent main workgroups' block counter (zeroed every step by ward_interleave_kernel)
     // phase A of the spare workgroups (each scans ONE slice of the row caches): matched rows, candidate streams, flags
     int32_t pa_flag[WB_R], pa_cnt[WB_R];           // pa_flag[wg] == epoch: slice wg has been published
@@ -144,11 +141,6 @@ struct icl_ward_ws {
     int64_t ld = 0;            // row pitch in floats (N rounded up to 64)
     float *nrm = nullptr;      // [capN] |E[r] - mu|^2 of the singletons: the scans' upper bounds of flagged entries (distance bounds)
     double *colsum = nullptr;  // [capD] column sums of E
-    float *mu = nullptr;       // [cn_stride] the centring vector (zero padded): bound body of the update kernel
-    int32_t *cand = nullptr;   // [WB_K][WB_CAND_CAP] candidate columns of the rows being created (bound body)
-    int32_t *rl_cnt = nullptr, *rl_col = nullptr; // [M], [M][WB_RL] nearest-neighbour lists of the merged clusters' rows (bound body)
-    float *rl_B = nullptr;     // [M] their cover bounds
-    size_t wxb_attr = 0;       // dynamic LDS the bound instantiation of the update kernel has been opted in for
     void *zero = nullptr;      // 256 zero bytes (LDS-DMA source of rows beyond n)
     int64_t dtri_floats = 0;
     int32_t *merges = nullptr; // [2*N]
@@ -176,7 +168,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mu, w->cand, w->rl_cnt, w->rl_col, w->rl_B};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero};
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -507,33 +499,15 @@ struct wrefine {
                       // decides how much is made exact ahead of need.  The initial row minima use a generous margin (the evaluations
                       // of one round run in parallel, one per thread: ~10 us whether 3 or 1000), so that the merge loop's rescans --
                       // which sit on the update kernel's critical path -- find the near entries exact already
-    // rows of MERGED clusters (ward_update_bound body): bounds too when upd != 0.  nrm then has an entry per creation id.
-    int upd;
-    const float *Crow;       // [S][d] centroids by slot
-    const int32_t *id_slot;  // creation id -> slot
-    float ceps_m, gam_m;     // the constants of pairs with a merged member (distance_mfma.hip, "merged clusters")
-    // The nearest-neighbour list of a merged cluster's row (ward_newrow_min_kernel): the columns of its <= WB_RL smallest entries --
-    // all VALUES -- and a cover bound rl_B: every other entry that was valid when the row was created has a lower bound >= rl_B.
-    // A later scan of the row that finds a valid listed entry strictly below rl_B has the row's first minimum without reading
-    // the row (scan_row_min); rl_cnt == 0: no list.
-    int32_t *rl_cnt;
-    float *rl_B;
-    int32_t *rl_col;         // [creation id][WB_RL]
 };
-#define WB_RL 16
 __device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
-// w2 = 2 fl(sa sb / (sa + sb)) (1 for two singletons); merged: the row belongs to a merged cluster
-__device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf, float w2 = 1.0f, bool merged = false)
+// upper bound of the value behind a flagged entry L of two singletons; ns = nrm[a] + nrm[b]
+__device__ __forceinline__ float wupper(float L, float ns, const wrefine &rf)
 {
-    // R <= (T + E_ab)(1 + g') w2,  w2 (T - E_ab) <= L (1 + 2 g')  (the store rounded L down by at most g' + 1e-6 relative):
-    // R <= (L (1 + 2 g') + 2 w2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
-    const float g = merged ? rf.gam_m : rf.gam, ce = merged ? rf.ceps_m : rf.ceps;
-    return (L * (1.0f + 3.0f * g) + 2.0001f * (w2 * ce) * ns) * (1.0f + 2.0f * g);
-}
-__device__ __forceinline__ float ward_w2(int sa, int sb)
-{
-    const float num = (float)((int64_t)sa * (int64_t)sb), den = (float)(sa + sb);
-    return 2.0f * (num / den);
+    // R <= (T + E_ab)(1 + g'),  T - E_ab <= L (1 + 2 g')  (the store rounded L down by at most g' + 1e-6 relative):
+    // R <= (L (1 + 2 g') + 2 E_ab)(1 + g'); the constants below leave room for this expression's own fp32 roundings
+    const float g = rf.gam, ce = rf.ceps;
+    return (L * (1.0f + 3.0f * g) + 2.0001f * ce * ns) * (1.0f + 2.0f * g);
 }
 // sum_k fl(fl(x_k - y_k)^2), strictly in k order, by ONE thread (d % 4 == 0): eight 16-byte loads of each row are in flight before
 // the first of them is used -- the loads depend on nothing, but issued one k-group at a time each waits for the round trip of the
@@ -672,7 +646,6 @@ __device__ __forceinline__ float ward_sqdist_wave(const float *__restrict__ x, c
     return s;
 }
 // where the centroid of cluster `id` stands during the merge loop (singletons of a singleton row: straight from E)
-__device__ __forceinline__ const float *wcentroid(const wrefine &rf, int id) { return rf.Crow + (int64_t)rf.id_slot[id] * rf.d; }
 __device__ __forceinline__ float ward_scale(float s, int sx, int sy)
 {
     const float num = (float)((int64_t)sx * (int64_t)sy); // :142
@@ -680,13 +653,6 @@ __device__ __forceinline__ float ward_scale(float s, int sx, int sy)
     return (num / den) * s;                                // :144
 }
 
-// the value behind a flagged entry of row my_id (size my_size; its centroid: my_cent, or looked up) against cluster c (size m)
-__device__ __forceinline__ float wpair_value(const wrefine &rf, int my_id, int my_size, const float *my_cent, int c, int m)
-{
-    if (my_id < rf.n) return ward_singleton_pair(rf.E, rf.d, my_id, c);
-    const float *y = my_cent ? my_cent : rf.Crow + (int64_t)rf.id_slot[my_id] * rf.d;
-    return ward_pair_value(rf.Crow + (int64_t)rf.id_slot[c] * rf.d, y, rf.d, m, my_size);
-}
 
 // visits columns [0, len) of a row: f(value, msz, mcid, column) with 4 x 16-byte loads of each stream in flight per lane
 template <typename F>
@@ -760,7 +726,7 @@ __device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float 
 
 __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine rf, float tv0, int ti0, float thr0, const float *my_cent, float *scr)
+                                             const wrefine rf, float tv0, int ti0, float thr0, float *scr)
 {
     // scr: 256 floats of LDS per wave of the workgroup (ward_sqdist_wave's scratch), 16-byte aligned
     // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
@@ -772,7 +738,6 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         return hit;
     };
     const float nme = rf.nrm[my_id];
-    const bool mrow = my_id >= rf.n;
     for (bool first = true;; first = false) {
         // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
         float tv = first ? tv0 : ICL_MAXF, ub = ICL_MAXF, lmin = first ? 0.0f : ICL_MAXF;
@@ -784,7 +749,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
                 const float L = fabsf(v);
                 lmin = L < lmin ? L : lmin; // (an excluded entry counted here only costs an empty pass B)
                 if (L < tv && L < ub) { // its upper bound (>= L) can only matter below this thread's best value and best upper bound
-                    const float up = wupper(L, nme + rf.nrm[c], rf, mrow ? ward_w2(m, my_size) : 1.0f, mrow); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
+                    const float up = wupper(L, nme + rf.nrm[c], rf); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
                     if (up < ub && !excluded(c)) ub = up;
                 }
             } else if (v < tv || (v == tv && c < ti)) {
@@ -824,12 +789,12 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         float rv = ICL_MAXF;
         int ri = -1;
         if ((rf.d & 3) == 0 && m <= 3 * (int)(blockDim.x >> 6)) { // a few entries: one per WAVE at a time (ward_sqdist_wave); many: one per thread
-            const float *yc = mrow ? (my_cent ? my_cent : wcentroid(rf, my_id)) : rf.E + (int64_t)my_id * rf.d;
+            const float *yc = rf.E + (int64_t)my_id * rf.d;
             for (int q = threadIdx.x >> 6; q < m; q += (int)(blockDim.x >> 6)) {
                 const int col = ref_col[q];
                 const int c = mcid[col];
-                const float *xc = mrow ? wcentroid(rf, c) : rf.E + (int64_t)c * rf.d;
-                const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr + (threadIdx.x >> 6) * 256), mrow ? msz[col] : 1, mrow ? my_size : 1);
+                const float *xc = rf.E + (int64_t)c * rf.d;
+                const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr + (threadIdx.x >> 6) * 256), 1, 1);
                 if ((threadIdx.x & 63) == 0) row[col] = val; // a value from now on
                 if (val < rv || (val == rv && c < ri)) {
                     rv = val;
@@ -840,7 +805,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         for (int q = threadIdx.x; q < m; q += blockDim.x) {
             const int col = ref_col[q];
             const int c = mcid[col];
-            const float val = wpair_value(rf, my_id, my_size, my_cent, c, msz[col]);
+            const float val = ward_singleton_pair(rf.E, rf.d, my_id, c);
             row[col] = val; // a value from now on
             if (val < rv || (val == rv && c < ri)) {
                 rv = val;
@@ -945,9 +910,9 @@ __device__ __forceinline__ void block_argmin2b(float &v0, int &i0, float &v1, in
 // more than WB_REF_CAP of them: its full loop).
 __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine &rf, float *scr, const float *my_cent = nullptr)
+                                             const wrefine &rf, float *scr)
 {
-    if (!(rf.E && (my_id < rf.n || rf.upd))) {
+    if (!(rf.E && my_id < rf.n)) { // only singleton rows ever hold bounds
         scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi);
         block_argmin(bv, bi, sv, si);
         return;
@@ -957,43 +922,6 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
         return hit;
     };
-    if (my_id >= rf.n && rf.rl_cnt && !my_cent) {
-        // a merged cluster's row: its nearest-neighbour list first (wave 0; columns are recycled, so every entry is re-validated:
-        // a column now owned by a younger cluster fails c < my_id, a dead one msz > 0)
-        const int k = rf.rl_cnt[my_id];
-        if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[k > 0 ? 8 : 10], 1ull);
-        if (k > 0) {
-            if (threadIdx.x < 64) {
-                float v = ICL_MAXF;
-                int c = -1;
-                if ((int)threadIdx.x < k) {
-                    const int col = rf.rl_col[(int64_t)my_id * WB_RL + threadIdx.x];
-                    const int m = msz[col], cc = mcid[col];
-                    const float e = row[col];
-                    if (m > 0 && m + my_size <= max_size && cc < my_id && !wflagged(e) && !excluded(cc)) {
-                        v = e;
-                        c = cc;
-                    }
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) argmin_combine(v, c, __shfl_down(v, off, 64), __shfl_down(c, off, 64));
-                if (threadIdx.x == 0) {
-                    sv[0] = v;
-                    si[0] = c;
-                }
-            }
-            __syncthreads();
-            const float lv_ = sv[0];
-            const int lc_ = si[0];
-            __syncthreads();
-            if (lc_ >= 0 && lv_ < rf.rl_B[my_id]) { // strictly below everything outside the list
-                bv = lv_;
-                bi = lc_;
-                if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[9], 1ull);
-                return;
-            }
-        }
-    }
     float tv = ICL_MAXF, lv = ICL_MAXF, lv2 = ICL_MAXF; // lv2: the second smallest lower bound (an excluded entry may count: it only errs low)
     int ti = -1, lc = -1;
     ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
@@ -1022,7 +950,6 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         return;
     }
     if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[0], 1ull);
-    const bool mrow = my_id >= rf.n;
     if ((rf.d & 3) == 0 && rf.margin == 0.0f) {
         // The entry with the smallest bound is evaluated straight away (one wave).  If the best value then lies strictly below the
         // SECOND smallest bound, every other flagged entry is strictly above it: done after one pass and one evaluation (the bounds
@@ -1030,9 +957,9 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         // collecting pass below.
         const int c = mcid[lc];
         if (threadIdx.x < 64) {
-            const float *yc = mrow ? (my_cent ? my_cent : wcentroid(rf, my_id)) : rf.E + (int64_t)my_id * rf.d;
-            const float *xc = mrow ? wcentroid(rf, c) : rf.E + (int64_t)c * rf.d;
-            const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr), mrow ? msz[lc] : 1, mrow ? my_size : 1);
+            const float *yc = rf.E + (int64_t)my_id * rf.d;
+            const float *xc = rf.E + (int64_t)c * rf.d;
+            const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr), 1, 1);
             if (threadIdx.x == 0) {
                 row[lc] = val; // a value from now on
                 sv[0] = val;
@@ -1054,12 +981,12 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
             bi = ti;
             return;
         }
-        scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, my_cent, scr);
+        scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, scr);
         return;
     }
-    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf, mrow ? ward_w2(msz[lc], my_size) : 1.0f, mrow);
+    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf);
     const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
-    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, my_cent, scr);
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, scr);
 }
 
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
@@ -1173,18 +1100,16 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
         st->B.ov_n = 0;
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
         for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
-        for (int j = 0; j < WB_K; ++j) {
-            st->B.ub2[j] = 0x7f7fffffu;
-            st->B.cand_n[j] = 0;
-        }
-        for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         st->B.blk_next = 0;
+#ifdef ICL_WARD_TIMERS
+        for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
         for (int j = 0; j < 3; ++j) st->B.dbg2[j] = 0;
         for (int j = 0; j < 4; ++j) st->B.dbg3[j] = st->B.dbg4[j] = 0;
         st->B.dbg4[3] = ~0ull;
         for (int j = 0; j < 4; ++j) st->B.dbg5[j] = 0;
         for (int j = 0; j < 8; ++j) st->B.dbg6[j] = 0;
-        for (int j = 0; j < 12; ++j) st->B.rf_stat[j] = 0;
+        for (int j = 0; j < 8; ++j) st->B.rf_stat[j] = 0;
+#endif
     }
 }
 
@@ -2300,350 +2225,6 @@ __global__ __launch_bounds__(WB_FD_THREADS) void ward_finish_data_kernel(int d, 
     static_assert(WB_K <= 16, "two chunks of 8 commits / picks");
 }
 
-// ---- BOUND body of the main workgroups (round 3) -------------------------------------------------------------------------
-// The exact rows cost 3 D unfused fp32 ops per (new cluster, live cluster) on the vector ALUs -- the update kernel ran at the
-// VALU issue rate, 2.5x above its HBM time.  With distance bounds in the matrix (distance_mfma.hip) the rows of the clusters
-// being created are written as PROVEN LOWER BOUNDS too: T = (n_x + n_c)/2 - x'.c' from v_mfma_f32_16x16x4_f32 (an fp32 fmaf
-// chain, bit for bit) over the mean-centred centroids, 16 new clusters x 16 live clusters per instruction.  The rows' minima
-// -- needed exactly by the finish kernel -- are then found by ward_newrow_min_kernel, which evaluates the reference's own
-// expression for the few entries whose bound sits in the band of the minimum; every other entry stays a flagged bound until a
-// later scan needs it (scan_row_min), and most never are.  Nothing the reference compares is taken from the matrix cores.
-//
-// Work split of a 64-cluster block: chain wave w = (column block cb = w & 3: clusters 16 cb .. 16 cb + 15) x (k half h = w >> 2:
-// G-steps 4h .. 4h+3 of every ring stage; a G-step = 4 k-groups = 16 k).  Lane l holds, per G-step, the float4 of k-group
-// 4G + (l >> 4) of live cluster (l & 15) [B operand] and of new cluster (l & 15) [A operand]: four MFMAs, one per component --
-// the k order inside the dot product is free, both operands use the same one.  The two halves' accumulators are added at the end
-// of the block (any summation order is inside the fma-chain bound gD).  The ring, the loaders, the cross-block prefetch and the
-// dirty-column handling are those of the exact body below; the centroid area of a stage holds [k-group][new cluster] float4.
-// |c'|^2 of the new clusters: the diagonal of their Gram matrix, by the same instruction on the same registers (column block 0's
-// two waves, in the workgroup's first block); every workgroup computes the same bits and stores them to nrm[] for later steps.
-#define WB_CAND_CAP 4096 /* columns a new row's candidate list holds (more: ward_newrow_min_kernel scans the row) */
-#define WB_LCAP 48       /* ... a workgroup collects per row before it appends to the global list directly */
-#define WB_NR_CAP 512    /* candidates ward_newrow_min_kernel ranks (more: it scans the row) */
-#define WB_LMARGIN 0.04f /* candidates are collected up to (1 + margin) x the threshold: ~16 nearest neighbours per row at N = 100 000 ResNet embeddings */
-struct wx_bound_args {
-    const float *mu;  // [>= 4 (dqp + WX_SG)] the centring vector of the distance bounds, zero padded
-    float *nrm;       // [n + merges] |centroid - mu|^2 by creation id
-    int32_t *cand;    // [WB_K][WB_CAND_CAP] candidate columns of the rows being created
-};
-
-__device__ __forceinline__ void wx_main_bound(float4 *wb_lds, int d, int dqp, int64_t S, float *__restrict__ CT, const float *__restrict__ Crow,
-                                              const float *__restrict__ cnewK, int64_t cn_stride, const int32_t *__restrict__ slot_id,
-                                              const int32_t *__restrict__ asz, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
-                                              float *__restrict__ Dtri, ward_state *__restrict__ st, int max_size, int64_t n, const wrefine &rf,
-                                              const wx_bound_args &ba)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
-    if (done || nb <= 0) return;
-    const int dirty_n0 = st->B.dirty_n, dirty_s0 = st->B.dirty_slot[lane & (2 * WB_K - 1)];
-    __shared__ int pa[WB_K], pb[WB_K], psc[WB_K];
-    __shared__ int64_t ro_l[WB_K];
-    __shared__ int nx_blk[2], nx_x[2][64], nx_sx[2][64], nx_mx[2][64], nx_dirty[2][64];
-    __shared__ float4 part[4][64];   // the accumulators of the upper k half, by column block
-    __shared__ float nrc_p[2][WB_K]; // |c'_j|^2 of the new clusters: the two k halves
-    __shared__ float ubc_l[WB_K];    // the rows' candidate thresholds as last seen (st->B.ub2: only ever lowered, so a stale value is a superset)
-    // candidates collected by this workgroup, flushed to the rows' global lists once, when its last block is done (a device
-    // atomic with a return value per candidate cost the epilogue 12 of its 15 us per block)
-    __shared__ int lc_cnt[WB_K], lc_col[WB_K][WB_LCAP];
-    __shared__ float lc_L[WB_K][WB_LCAP];
-    if (threadIdx.x < WB_K) lc_cnt[threadIdx.x] = 0;
-    if (threadIdx.x < WB_K) {
-        pa[threadIdx.x] = st->B.a[threadIdx.x];
-        pb[threadIdx.x] = st->B.b[threadIdx.x];
-        psc[threadIdx.x] = st->B.sa[threadIdx.x] + st->B.sb[threadIdx.x];
-        ro_l[threadIdx.x] = (int)threadIdx.x < nb ? rowoff[n + t + threadIdx.x] : 0;
-    }
-    const int nstage = (dqp + WX_SG - 1) / WX_SG;
-    float4 *mu_l = wb_lds + WX_R * WX_STAGE_F4; // the centring vector, by k-group
-    for (int g = threadIdx.x; g < nstage * WX_SG; g += WX_THREADS) mu_l[g] = reinterpret_cast<const float4 *>(ba.mu)[g];
-    __syncthreads();
-    int pf_done = 0, pf_raw = 0, pf_blk = -1, pf_xr = -1, pf_x = -1, pf_sx = 0, pf_mx = 0, pf_dirty = 0; // chain wave 0 only
-    auto pf_advance = [&](const int upto, const int par) { // (the exact body's prefetch of the next block's state: see there)
-        if (pf_done < 1 && upto >= 1) { // every block comes from the counter, the first one too: a workgroup that starts late (its CU ran a
-            // spare / preselection workgroup first) must not sit on a reserved block while the others run out of work
-            pf_raw = lane == 0 ? atomicAdd(&st->B.blk_next, 1) : 0;
-            pf_done = 1;
-        }
-        if (pf_done < 2 && upto >= 2) {
-            int r = pf_raw;
-            asm volatile("" : "+v"(r));
-            pf_blk = __builtin_amdgcn_readfirstlane(r);
-            const bool on = (int64_t)pf_blk * 64 < nlive;
-            const int sl = pf_blk * 64 + lane;
-            pf_dirty = 0;
-            const int nd = on ? dirty_n0 : 0;
-            for (int z = 0; z < nd; ++z) pf_dirty |= __builtin_amdgcn_readlane(dirty_s0, z) == sl;
-            pf_xr = on ? slot_id[sl] : -1;
-            pf_done = 2;
-        }
-        if (pf_done < 3 && upto >= 3) {
-            pf_x = ((int64_t)pf_blk * 64 + lane < nlive) ? pf_xr : -1;
-            pf_sx = pf_x >= 0 ? asz[pf_x] : 0;
-            pf_mx = pf_x >= 0 ? mcol[pf_x] : 0;
-            pf_done = 3;
-        }
-        if (pf_done < 4 && upto >= 4) {
-            if (lane == 0) nx_blk[par] = pf_blk;
-            nx_x[par][lane] = pf_x;
-            nx_sx[par][lane] = pf_sx;
-            nx_mx[par][lane] = pf_mx;
-            nx_dirty[par][lane] = pf_dirty;
-            pf_done = 4;
-        }
-    };
-    if (wave == 0) pf_advance(4, 0);
-    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
-    int rp = 0;
-    bool pre = false;
-    bool gram_done = false; // the new clusters' norms are in nrc_p (computed in this workgroup's first computed block)
-    const bool loader = wave >= WX_CW;
-    const int pj = wave - WX_CW;
-    const int cb = wave & 3, hk = (wave >> 2) & 1; // chain waves: column block, k half
-    const int lc = lane & 15, lq = lane >> 4;
-    const unsigned ring_base = lds_addr_of(wb_lds);
-    const int dq_real = d >> 2;
-    for (int blk_it = 0;; ++blk_it) {
-        const int par = blk_it & 1;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int64_t mblk = __builtin_amdgcn_readfirstlane(nx_blk[par]);
-        rp = __builtin_amdgcn_readfirstlane(rp);
-        pf_done = 0;
-        if (mblk < 0 || mblk * 64 >= nlive) {
-            // flush this workgroup's candidates (every epilogue has passed the barrier above): one thread per row keeps what the
-            // threshold as it stands now still admits -- any value read here is >= the final one -- and appends with ONE atomic
-            if (threadIdx.x < WB_K && lc_cnt[threadIdx.x] > 0) {
-                const int j = threadIdx.x, cnt = lc_cnt[j] < WB_LCAP ? lc_cnt[j] : WB_LCAP;
-                const float thr = __uint_as_float(__hip_atomic_load(&st->B.ub2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                int k = 0;
-                const float thr_m = thr < 1e37f ? thr * (1.0f + WB_LMARGIN) : thr;
-                for (int i = 0; i < cnt; ++i) k += lc_L[j][i] <= thr_m ? 1 : 0;
-                if (k > 0) {
-                    int at = atomicAdd(&st->B.cand_n[j], k);
-                    for (int i = 0; i < cnt; ++i)
-                        if (lc_L[j][i] <= thr_m) {
-                            if (at < WB_CAND_CAP) ba.cand[j * WB_CAND_CAP + at] = lc_col[j][i];
-                            ++at;
-                        }
-                }
-            }
-            WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg3[3], wall_clock64());)
-            WB_TIMER(if (threadIdx.x == 0) atomicMin(&st->B.dbg4[3], tm0);)
-            WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[1] += wall_clock64() - tm0;)
-            WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) st->B.dbg[2] += wall_clock64() - tm0;)
-            break;
-        }
-        const int64_t slot = mblk * 64 + lane;
-        const bool dirty_lane = nx_dirty[par][lane] != 0;
-        const bool any_dirty = __any(dirty_lane);
-        const char *ctb = reinterpret_cast<const char *>(CT);
-        const int64_t row_bytes = S * 16;
-        // new clusters' pieces: the stage's centroid area is [k-group][new cluster] float4; piece q holds k-groups 4q .. 4q+3:
-        // lane l fetches k-group 4q + l/16 of new cluster l%16 (lands lane-linear = at (4q + l/16) * 16 + l%16)
-        auto csrc_of = [&](int q, int stage) -> const char * {
-            return reinterpret_cast<const char *>(cnewK) + ((int64_t)lc * cn_stride + ((int64_t)stage * WX_SG + 4 * q + lq) * 4) * 4;
-        };
-        auto issue = [&](int stage, int phase, int64_t slot_l, bool dirty_l) {
-            const int g0 = stage * WX_SG + pj * WX_XOPS;
-            const unsigned sbase = ring_base + (unsigned)(((phase + stage) % WX_R) * WX_STAGE_F4 * 16);
-#pragma unroll
-            for (int q = 0; q < WX_XOPS; ++q) {
-                const int g = g0 + q;
-                const char *src = ctb + (int64_t)g * row_bytes + slot_l * 16;
-                if (dirty_l && g < dq_real) src = reinterpret_cast<const char *>(Crow) + ((int64_t)slot_l * d + (int64_t)g * 4) * 4;
-                glds16_asm(src, sbase + (unsigned)((pj * WX_XOPS + q) * 1024));
-            }
-#pragma unroll
-            for (int q = 0; q < WX_COPS; ++q)
-                glds16_asm(csrc_of(pj * WX_COPS + q, stage), sbase + (unsigned)(WX_SG * 1024 + (pj * WX_COPS + q) * 1024));
-        };
-        const bool xblk = nstage >= 8;
-        const int iD = xblk ? (3 * nstage) / 4 - 1 : nstage - 1;
-        if (loader && !pre)
-            for (int i = 0; i < WX_R - 1 && i < nstage; ++i) issue(i, rp, slot, dirty_lane);
-        // which rows does this lane's cluster (lane = slot of the block) take part in?  Every wave computes the same masks.
-        const int x = nx_x[par][lane], sx = nx_sx[par][lane];
-        unsigned okmask = 0;
-        bool survives;
-        {
-            bool alive = x >= 0 && sx > 0;
-#pragma unroll
-            for (int j = 0; j < WB_K; ++j) {
-                if (j < nb) {
-                    alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
-                    if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
-                }
-            }
-            survives = alive; // not a member of any pick of the batch
-        }
-        if (wave == WX_CW - 1 && lane < WB_K) // (a chain wave without an epilogue; the stage barriers order this against the epilogue's reads)
-            ubc_l[lane] = __uint_as_float(__hip_atomic_load(&st->B.ub2[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (!__any(okmask != 0)) {
-            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (wave == 0) pf_advance(4, par ^ 1);
-            rp = (rp + (WX_R - 1 < nstage ? WX_R - 1 : nstage)) % WX_R;
-            pre = false;
-            unsigned long long dm = __ballot(dirty_lane);
-            while (dm) {
-                const int l = __ffsll((long long)dm) - 1;
-                dm &= dm - 1;
-                const int64_t sl = mblk * 64 + l;
-                for (int g = threadIdx.x + 2 * WB_SG; g < dq_real; g += WX_THREADS)
-                    *reinterpret_cast<float4 *>(CT + ct4_off(g, S, sl)) = reinterpret_cast<const float4 *>(Crow + sl * d)[g];
-            }
-            continue;
-        }
-        // this lane's column in the epilogue: cluster 16 cb + lc of the block (chain waves of the lower k half)
-        const int ex_ = nx_x[par][cb * 16 + lc];
-        float nrm_x = 0.0f;
-        if (!loader && hk == 0 && ex_ >= 0) nrm_x = ba.nrm[ex_]; // (in flight during the whole block)
-        const bool gram = !loader && cb == 0 && !gram_done;
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0, gr0 = acc0, gr1 = acc0;
-        auto consume = [&](int stage) {
-            const float4 *sb_ = wb_lds + ((rp + stage) % WX_R) * WX_STAGE_F4;
-            const float4 *xr = sb_ + cb * 16 + lc;
-            const float4 *ar = sb_ + WX_SG * 64 + lc;
-            const float4 *mr = mu_l + stage * WX_SG;
-#pragma unroll
-            for (int gg = 0; gg < WX_SG / 8; ++gg) {
-                const int g = 4 * (hk * (WX_SG / 8) + gg) + lq; // this lane's k-group of the stage
-                const float4 xv = xr[g * 64], av = ar[g * 16], mv = mr[g];
-                const float x0 = xv.x - mv.x, x1 = xv.y - mv.y, x2 = xv.z - mv.z, x3 = xv.w - mv.w; // fl(x - mu): the centred operands
-                const float a0 = av.x - mv.x, a1 = av.y - mv.y, a2 = av.z - mv.z, a3 = av.w - mv.w;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, x2, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, x3, acc1, 0, 0, 0);
-                if (gram) {
-                    gr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, gr0, 0, 0, 0);
-                    gr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, gr1, 0, 0, 0);
-                    gr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, a2, gr0, 0, 0, 0);
-                    gr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, a3, gr1, 0, 0, 0);
-                }
-            }
-        };
-        int nxt_blk = -1;
-        bool nxt_on = false, nxt_dirty = false;
-        WB_TIMER(const unsigned long long ts0 = wall_clock64();)
-        for (int i = 0; i < nstage; ++i) {
-            if (loader) {
-                if (i + WX_R - 2 < nstage || nxt_on)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WX_R - 2) * WX_OPS) : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (wave == 0) pf_advance(i == 0 ? 1 : i == (nstage >> 2) ? 2 : i == (nstage >> 1) ? 3 : i == iD ? 4 : 0, par ^ 1);
-            if (xblk && i == iD + 1) {
-                nxt_blk = __builtin_amdgcn_readfirstlane(nx_blk[par ^ 1]);
-                nxt_on = (int64_t)nxt_blk * 64 < nlive;
-                nxt_dirty = nxt_on && nx_dirty[par ^ 1][lane] != 0;
-            }
-            if (loader) {
-                if (any_dirty && i * WX_SG >= 2 * WB_SG) {
-                    const float4 *xr = wb_lds + ((rp + i) % WX_R) * WX_STAGE_F4 + lane;
-#pragma unroll
-                    for (int q = 0; q < WX_XOPS; ++q) {
-                        const int g = i * WX_SG + pj * WX_XOPS + q;
-                        if (dirty_lane && g < dq_real) *reinterpret_cast<float4 *>(CT + ct4_off(g, S, slot)) = xr[(pj * WX_XOPS + q) * 64];
-                    }
-                }
-                if (i + WX_R - 1 < nstage)
-                    issue(i + WX_R - 1, rp, slot, dirty_lane);
-                else if (nxt_on)
-                    issue(i + WX_R - 1 - nstage, rp + nstage, (int64_t)nxt_blk * 64 + lane, nxt_dirty);
-            } else {
-                consume(i);
-            }
-        }
-        if (wave == 0) pf_advance(4, par ^ 1);
-        rp = (rp + nstage) % WX_R;
-        pre = nxt_on;
-        WB_TIMER(const unsigned long long ts1 = wall_clock64();)
-        WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) { st->B.dbg3[0] += ts1 - ts0; st->B.dbg3[2] += 1; })
-        // ---- the two k halves meet: the upper half's sums (and the norms' halves) go through LDS
-        f32x4 acc = acc0 + acc1;
-        if (!loader && hk == 1) part[cb][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        if (gram) {
-            const f32x4 gr = gr0 + gr1;
-            const int v = lc - 4 * lq; // the diagonal element of this lane's column, if it holds it: row 4 lq + v == lc
-            if (v >= 0 && v < 4) nrc_p[hk][lc] = v == 0 ? gr[0] : v == 1 ? gr[1] : v == 2 ? gr[2] : gr[3];
-        }
-        gram_done = true;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (loader || hk != 0) continue;
-        if (gram && lane < nb) ba.nrm[n + t + lane] = nrc_p[0][lane] + nrc_p[1][lane]; // (every workgroup stores the same bits)
-        {
-            const float4 o = part[cb][lane];
-            acc[0] += o.x;
-            acc[1] += o.y;
-            acc[2] += o.z;
-            acc[3] += o.w;
-        }
-        // nrm_x has been in flight since the block began: ONE wait here.  Left to the compiler, every use inside the conditional code
-        // below waits with vmcnt(0) again -- by then for the scattered stores of the previous row (4 x 2.5 us per block).
-        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0" : "+v"(nrm_x)::"memory");
-        const unsigned okm = (unsigned)__shfl((int)okmask, cb * 16 + lc, 64);
-        const bool surv_e = __shfl((int)survives, cb * 16 + lc, 64) != 0;
-        const int sxe = nx_sx[par][cb * 16 + lc];
-        const int mxe = nx_mx[par][cb * 16 + lc];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int j = 4 * lq + v; // the new cluster c_j
-            const bool valid = j < nb && ((okm >> j) & 1u);
-            float L = 0.0f, U = ICL_MAXF;
-            if (valid) {
-                const int sc = psc[j];
-                const float ns = nrm_x + (nrc_p[0][j] + nrc_p[1][j]);
-                const float T = 0.5f * ns - acc[v];
-                const float num = (float)((int64_t)sxe * (int64_t)sc), den = (float)(sxe + sc);
-                const float w2 = 2.0f * (num / den);
-                // 2 w (T - E)(1 - g'), pushed down against the roundings of this expression itself (distance_mfma.hip, "merged clusters")
-                L = (T - rf.ceps_m * ns) * (1.0f - rf.gam_m);
-                L = w2 * L;
-                L = L * (1.0f - 6e-7f);
-                L = (L > 1e-30f && ns < 1e37f) ? L : 0.0f; // subnormal range / overflowing norms (also NaN): no claim
-                Dtri[ro_l[j] + mxe] = __uint_as_float(__float_as_uint(L) | 0x80000000u);
-                if (surv_e) {
-                    U = wupper(L, ns, rf, w2, true);
-                    U = U < ICL_MAXF ? U : ICL_MAXF; // (NaN / +inf: no claim)
-                }
-            }
-            // candidates of the row's minimum: the threshold is the smallest upper bound seen so far among the survivors (the row's
-            // minimum over them cannot exceed it); whatever is at or below it when written -- and every entry of a later pick's
-            // member -- goes on the row's list, a superset of the final band (ward_newrow_min_kernel filters with the final value)
-            float Um = U; // minimum over the 16 lanes of this lane's row group (DPP: quad swaps, then the row's mirrors)
-            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0xB1, 0xf, 0xf, false)));  // quad_perm:[1,0,3,2]
-            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x4E, 0xf, 0xf, false)));  // quad_perm:[2,3,0,1]
-            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x141, 0xf, 0xf, false))); // row_half_mirror
-            Um = fminf(Um, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Um), __float_as_int(Um), 0x140, 0xf, 0xf, false))); // row_mirror
-            float thr = ubc_l[j & (WB_K - 1)];
-            if (Um < thr) {
-                if (lc == 0) {
-                    atomicMin(&st->B.ub2[j], __float_as_uint(Um));
-                    ubc_l[j] = Um;
-                }
-                thr = Um;
-            }
-            if (valid && (!surv_e || L <= thr * (1.0f + WB_LMARGIN))) { // (the margin: the row's nearest-neighbour list, ward_newrow_min_kernel)
-                const int at = atomicAdd(&lc_cnt[j], 1);
-                if (at < WB_LCAP) {
-                    lc_col[j][at] = mxe;
-                    lc_L[j][at] = L;
-                } else {
-                    const int ag = atomicAdd(&st->B.cand_n[j], 1);
-                    if (ag < WB_CAND_CAP) ba.cand[j * WB_CAND_CAP + ag] = mxe;
-                }
-            }
-        }
-        WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg3[1] += wall_clock64() - ts1;)
-    } // block loop
-}
-
-template <bool BOUND>
 __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d, int dqp, int64_t S, float *__restrict__ CT,
                                                                       const float *__restrict__ Crow, const float *__restrict__ cnewK,
                                                                       const float *__restrict__ cnewI, int64_t cn_stride,
@@ -2653,14 +2234,9 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                                                                       const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                                                       float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf,
-                                                                      const wx_bound_args ba)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4 (+ the centring vector: bound body)
-    if (BOUND && blockIdx.x >= WB_R + 2) { // main workgroups of the bound mode; the virtual slots' few rows stay exact (body below)
-        wx_main_bound(wb_lds, d, dqp, S, CT, Crow, cnewK, cn_stride, slot_id, asz, rowoff, mcol, Dtri, st, max_size, n, rf, ba);
-        return;
-    }
+    extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
@@ -2952,165 +2528,6 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
     } // block loop
-}
-
-// Bound mode, after the update: the minima of the rows just written (all bounds), one workgroup per new cluster c_j.
-//   ckey[j]:  first minimum over the clusters alive at c_j's time (members of LATER picks included) -- what the validation needs
-//   ckey2[j]: ... over the clusters that survive the whole batch -- the row's cache after a full commit
-// The batch is not committed yet: the columns still carry the names and sizes of the clusters before it, so the members of the
-// picks up to j (gone at c_j's time; the columns of a_0..a_{j-1} hold the virtual-slot entries D(c_j, c_i), whose keys the virtual
-// workgroup has already merged in) are excluded by name.  The second scan only runs when the first minimum is a later pick's member.
-__global__ __launch_bounds__(1024) void ward_newrow_min_kernel(int64_t n, const float *__restrict__ cnewK, int64_t cn_stride,
-                                                              const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
-                                                              const int32_t *__restrict__ mcid, float *__restrict__ Dtri, ward_state *__restrict__ st,
-                                                              int max_size, const wrefine rf, const int32_t *__restrict__ cand,
-                                                              const int32_t *__restrict__ mcol)
-{
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    __shared__ int ex[2 * WB_K];
-    __shared__ int nref;
-    __shared__ int rcol[WB_NR_CAP], rcid[WB_NR_CAP], rmsz[WB_NR_CAP], rslot[WB_NR_CAP];
-    __shared__ float rval[WB_NR_CAP];
-    __shared__ int evq[WB_NR_CAP], rlat[WB_NR_CAP], rl_tmp[WB_RL], nev, nlist;
-    __shared__ unsigned covB;
-    __shared__ __attribute__((aligned(16))) float scr[16][256];
-    const int j = blockIdx.x;
-    if (st->done) return;
-    const int nb = st->B.nb, t = st->t;
-    if (j >= nb) return;
-    WB_TIMER(const unsigned long long tn0 = wall_clock64();)
-    if (threadIdx.x < 2 * WB_K) {
-        const int q = threadIdx.x >> 1;
-        ex[threadIdx.x] = q < nb ? ((threadIdx.x & 1) ? st->B.b[q] : st->B.a[q]) : -1;
-    }
-    if (threadIdx.x == 0) nref = 0;
-    __syncthreads();
-    const int my_id = (int)(n + t + j), my_size = st->B.sa[j] + st->B.sb[j];
-    float *row = Dtri + rowoff[my_id];
-    const float *cent = cnewK + (int64_t)j * cn_stride;
-    auto member = [&](int c, int z0) { // is c a member of a pick z0/2 or later?
-        bool hit = false;
-        for (int z = z0; z < 2 * nb; ++z) hit |= ex[z] == c;
-        return hit;
-    };
-    float v1 = ICL_MAXF, v2 = ICL_MAXF;
-    int i1 = -1, i2 = -1;
-    const int cn = st->B.cand_n[j];
-    bool listed = cn <= WB_CAND_CAP && (rf.d & 3) == 0;
-    const float thr = __uint_as_float(st->B.ub2[j]);
-    const float thr_m = thr < 1e37f ? thr * (1.0f + WB_LMARGIN) : thr;
-    if (listed) {
-        // The list the update kernel's workgroups left.  The FINAL threshold thr is the smallest upper bound among the survivors: the
-        // row's minimum over them -- and with it the minimum over all clusters alive at c_j's time -- cannot exceed it, so the
-        // entries with a bound <= thr (the band) decide both minima.  Candidates up to (1 + margin) thr are kept as well: the
-        // survivors among them are the row's nearest neighbours.
-        for (int q = threadIdx.x; q < cn; q += blockDim.x) {
-            const int col = cand[j * WB_CAND_CAP + q];
-            const float v = row[col];
-            if (fabsf(v) <= thr_m) {
-                const int at = atomicAdd(&nref, 1);
-                if (at < WB_NR_CAP) { // everything the evaluation needs, fetched here by as many threads as there are candidates
-                    const int c = mcid[col];
-                    rcol[at] = col;
-                    rcid[at] = c;
-                    rmsz[at] = msz[col];
-                    rslot[at] = rf.id_slot[c];
-                    rval[at] = v;
-                }
-            }
-        }
-        __syncthreads();
-        listed = nref <= WB_NR_CAP;
-    }
-    WB_TIMER(if (threadIdx.x == 0 && j == 0) st->B.dbg2[1] += wall_clock64() - tn0;)
-    if (listed) {
-        // rank the survivors by lower bound: the WB_RL smallest form the row's nearest-neighbour list, the smallest bound among the
-        // others (or the collection limit) is its cover bound.  Evaluated: the list, and whatever else lies in the band.
-        const int m = nref;
-        if (threadIdx.x == 0) {
-            nev = 0;
-            nlist = 0;
-            covB = __float_as_uint(thr_m);
-        }
-        for (int i = threadIdx.x; i < m; i += blockDim.x) rlat[i] = member(rcid[i], 0) ? 1 : 0; // (members of the picks up to j never enter the lists: okmask)
-        __syncthreads();
-        // the virtual-slot entries D(c_j, c_i), i < j, are values outside the list: they lower the cover bound
-        if ((int)threadIdx.x < j) {
-            const int i = threadIdx.x, sci = st->B.sa[i] + st->B.sb[i];
-            if (sci + my_size <= max_size) {
-                const float v = row[mcol[ex[2 * i]]];
-                if (v >= 0.0f) atomicMin(&covB, __float_as_uint(v)); // (NaN: never a minimum)
-            }
-        }
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            const float Li = fabsf(rval[i]);
-            const bool later = rlat[i] != 0;
-            int rank = 0;
-            if (!later)
-                for (int q = 0; q < m; ++q) {
-                    const float Lq = fabsf(rval[q]);
-                    rank += (Lq < Li || (Lq == Li && q < i)) && !rlat[q] ? 1 : 0;
-                }
-            const bool in_list = !later && rank < WB_RL;
-            if (!later && !in_list) atomicMin(&covB, __float_as_uint(Li));
-            if (in_list) rl_tmp[atomicAdd(&nlist, 1)] = rcol[i];
-            if (in_list || Li <= thr) evq[atomicAdd(&nev, 1)] = i;
-        }
-        __syncthreads();
-        const int ne = nev;
-        if (rf.stat && threadIdx.x == 0) {
-            atomicAdd(&rf.stat[0], 1ull);
-            atomicAdd(&rf.stat[2], 1ull);
-            atomicAdd(&rf.stat[3], (unsigned long long)ne);
-        }
-        for (int e = threadIdx.x >> 6; e < ne; e += (int)(blockDim.x >> 6)) { // one entry per wave at a time
-            const int q = evq[e];
-            const int col = rcol[q];
-            const int c = rcid[q];
-            float val = rval[q];
-            if (wflagged(val)) {
-                val = ward_scale(ward_sqdist_wave(rf.Crow + (int64_t)rslot[q] * rf.d, cent, rf.d, scr[threadIdx.x >> 6]), rmsz[q], my_size);
-                if ((threadIdx.x & 63) == 0) row[col] = val; // a value from now on
-            }
-            if (val < v1 || (val == v1 && c < i1)) {
-                v1 = val;
-                i1 = c;
-            }
-            if (!member(c, 0) && (val < v2 || (val == v2 && c < i2))) {
-                v2 = val;
-                i2 = c;
-            }
-        }
-        block_argmin2(v1, i1, v2, i2, sv, si);
-        // the row's list for later scans (scan_row_min)
-        if (threadIdx.x < WB_RL && (int)threadIdx.x < nlist) rf.rl_col[(int64_t)my_id * WB_RL + threadIdx.x] = rl_tmp[threadIdx.x];
-        if (threadIdx.x == 0) {
-            rf.rl_cnt[my_id] = nlist;
-            rf.rl_B[my_id] = __uint_as_float(covB);
-        }
-    } else {
-        // too many candidates (heavy ties): scan the row.  The second scan only runs when the first minimum is a later pick's member.
-        scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * (j + 1), v1, i1, sv, si, rf, &scr[0][0], cent);
-        v2 = v1;
-        i2 = i1;
-        if (i1 >= 0 && member(i1, 2 * (j + 1))) scan_row_min(row, n, msz, mcid, my_id, my_size, max_size, ex, 2 * nb, v2, i2, sv, si, rf, &scr[0][0], cent);
-        if (threadIdx.x == 0) rf.rl_cnt[my_id] = 0;
-    }
-    if (threadIdx.x == 0) {
-        if (i1 >= 0 && v1 < ICL_MAXF) atomicMin(&st->B.ckey[j], ((unsigned long long)__float_as_uint(v1) << 32) | (unsigned)i1);
-        if (i2 >= 0 && v2 < ICL_MAXF) atomicMin(&st->B.ckey2[j], ((unsigned long long)__float_as_uint(v2) << 32) | (unsigned)i2);
-        WB_TIMER(if (j == 0) st->B.dbg2[2] += wall_clock64() - tn0;)
-    }
-}
-
-// the centring vector of the distance bounds, exactly as dist_center_kernel forms it (distance_mfma.hip); mu is zero beyond d
-__global__ void ward_mu_kernel(const double *__restrict__ colsum, int64_t n, int d, float *__restrict__ mu)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= d) return;
-    const double inv_n = 1.0 / (double)n;
-    mu[k] = (float)(colsum[k] * inv_n);
 }
 
 // FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
@@ -3448,7 +2865,6 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             rowmin[b] = ICL_MAXF;
             rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
             rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
-            if (J != nbp && rf.rl_cnt) rf.rl_cnt[c] = 0; // the members of the picks that did not commit live on: the row's list does not cover them
         }
         if (full0 && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
             rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
@@ -3546,8 +2962,6 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                         st->B.sb[j] = ls.B.pre_sb[j];
                         st->B.val[j] = ls.B.pre_val[j];
                         st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
-                        st->B.ub2[j] = 0x7f7fffffu; // MaxFloat32
-                        st->B.cand_n[j] = 0;
                         rowmin[n + t1 + j] = ICL_MAXF; // rows being created are not selectable yet
                         rowoff[n + t1 + j] = (J == WB_K && t1 + j >= WB_K) ? pf_ro : ward_new_row(n, ld, t1 + j, t0, ls.B.a, merges, rowoff);
                     } else if (lane >= WB_K && lane < WB_K + np)
@@ -3904,8 +3318,6 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             st->B.sb[j] = pk_sb[j];
             st->B.val[j] = pk_v[j];
             st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
-            st->B.ub2[j] = 0x7f7fffffu;
-            st->B.cand_n[j] = 0;
             rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
             rowoff[n + t + j] = ward_new_row(n, ld, t + j, t0, ls.B.a, merges, rowoff);
         }
@@ -4007,11 +3419,7 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mu, w->cand, w->rl_cnt, w->rl_col, w->rl_B};
-        w->mu = nullptr;
-        w->cand = nullptr;
-        w->rl_cnt = w->rl_col = nullptr;
-        w->rl_B = nullptr;
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero};
         w->nrm = nullptr;
         w->colsum = nullptr;
         w->zero = nullptr;
@@ -4054,13 +3462,7 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(rownn, int32_t, w->M);
         WS_ALLOC(rowoff, int64_t, w->M + 1);
         WS_ALLOC(mcol, int32_t, w->M);
-        WS_ALLOC(nrm, float, w->M); // by creation id (merged clusters: written by the update kernel's bound body)
-        ICL_HIP(ctx, hipMemsetAsync(w->nrm, 0, (size_t)w->M * sizeof(float), ctx->stream));
-        WS_ALLOC(mu, float, w->cn_stride);
-        WS_ALLOC(cand, int32_t, WB_K * WB_CAND_CAP);
-        WS_ALLOC(rl_cnt, int32_t, w->M);
-        WS_ALLOC(rl_B, float, w->M);
-        WS_ALLOC(rl_col, int32_t, w->M * WB_RL);
+        WS_ALLOC(nrm, float, n + 4); // |E[r] - mu|^2 of the singletons
         WS_ALLOC(colsum, double, dd);
         WS_ALLOC(zero, char, 256);
         ICL_HIP(ctx, hipMemsetAsync(w->zero, 0, 256, ctx->stream));
@@ -4348,7 +3750,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // Exact mode, the rows this call computes itself: by default PROVEN LOWER BOUNDS from the matrix cores, made exact on demand by
     // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
     // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
-    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f, 0, nullptr, nullptr, 0.0f, 0.0f, nullptr, nullptr, nullptr};
+    wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
     struct free_guard {
         void *p = nullptr;
         ~free_guard() { if (p) (void)hipFree(p); }
@@ -4362,20 +3764,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         if (hipMalloc(&g_ec.p, (size_t)n * K * 4) != hipSuccess) return icl_fail(ctx, ICL_ERR_NOMEM, "centred copy of E (%lld x %d floats)", (long long)n, K);
         const double u = 5.9604644775390625e-08; // 2^-24
         const double gD = K * u / (1.0 - K * u), gp = std::pow(1.0 + u, d + 2) - 1.0;
-        rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)),
-                     getenv("ICL_WARD_STATS") ? &w->st->B.rf_stat[0] : nullptr, 0.0f, 0, w->Crow, w->id_slot, 0.0f, 0.0f, nullptr, nullptr, nullptr};
-        {
-            // pairs with a merged member (the update kernel's bound body): chains of at most Dm products (the ring's whole stages) and the
-            // sums of the two k halves / two accumulators; the merged clusters' norms come from the same kind of chain:
-            //   | T - S/2 | <= (gDm + 16 u)(|a'|^2 + |b'|^2),  |a'|^2 <= n_a / (1 - gDm);   R in w S (1 -+ g_m), g_m = (1 + u)^(D + 8) - 1
-            const double Dm = (double)((wb_groups(d) + WX_SG - 1) / WX_SG * WX_SG) * 4 + 4;
-            const double gDm = Dm * u / (1.0 - Dm * u);
-            rf.ceps_m = (float)((gDm + 16 * u) * (1 + 2 * gDm + 64 * u) * (1 + 1e-6));
-            rf.gam_m = (float)((std::pow(1.0 + u, d + 8) - 1.0) * (1 + 1e-6));
-        }
+        unsigned long long *stat = nullptr;
+#ifdef ICL_WARD_TIMERS
+        if (getenv("ICL_WARD_STATS")) stat = &w->st->B.rf_stat[0];
+#endif
+        rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)), stat, 0.0f};
         ICL_TRY(icl_dist_center_launch(ctx, d_E, n, d, K, w->colsum, (float *)g_ec.p, w->nrm, ctx->stream));
-        ICL_HIP(ctx, hipMemsetAsync(w->mu, 0, (size_t)w->cn_stride * sizeof(float), ctx->stream));
-        hipLaunchKernelGGL(ward_mu_kernel, dim3((unsigned)icl_ceil_div(d, 256)), dim3(256), 0, ctx->stream, w->colsum, n, d, w->mu);
         ICL_TRY(icl_dist_bound_launch(ctx, (const float *)g_ec.p, w->nrm, w->zero, n, K, rf.ceps, rf.gam, w->Dtri, w->rowoff, own_lo / DT_TILE,
                                       icl_ceil_div(own_hi, DT_TILE), ctx->stream));
     } else
@@ -4451,30 +3845,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // main workgroups: persistent, at most one per CU (they draw blocks from a counter); fewer when the input has fewer blocks
         const unsigned wx_blocks = (unsigned)std::min<int64_t>(w->S / 64, (int64_t)ctx->prop.multiProcessorCount) + 2 + WB_R;
         if (!w->wx_attr) { // per context, i.e. per device: a group drives one context per GPU
-            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
+            ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             w->wx_attr = true;
         }
-        // Bound body of the update kernel (rows of the new clusters as lower bounds from the matrix cores): when icl_set_ward_options
-        // asks for it (ICL_DIST_BOUND) and the shape fits (whole k-groups; ring + centring vector + static arrays inside the CU's 160 KB)
-        const size_t wxb_lds_bytes = wx_lds_bytes + (size_t)((dqb + WX_SG - 1) / WX_SG * WX_SG) * 16;
-        bool upd_bound = !lw && rf.E && (d & 3) == 0 && ctx->ward_dist == 2; // measured slower end to end than the exact rows at N = 100 000 and 250 000: on request only
-        if (upd_bound) {
-            hipFuncAttributes fa;
-            ICL_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)ward_update_batch2_kernel<true>));
-            if (wxb_lds_bytes + fa.sharedSizeBytes > 160 * 1024) upd_bound = false;
-            else if (w->wxb_attr < wxb_lds_bytes) {
-                ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wxb_lds_bytes));
-                w->wxb_attr = wxb_lds_bytes;
-            }
-        }
-        rf.upd = upd_bound ? 1 : 0;
-        if (upd_bound) {
-            rf.rl_cnt = w->rl_cnt;
-            rf.rl_B = w->rl_B;
-            rf.rl_col = w->rl_col;
-            ICL_HIP(ctx, hipMemsetAsync(w->rl_cnt, 0, (size_t)w->M * sizeof(int32_t), ctx->stream));
-        }
-        const wx_bound_args wba{w->mu, w->nrm, w->cand};
         // the express step's data phase runs in ward_finish_data_kernel from a record the finish kernel leaves behind cnewI
         int32_t *fdrec = (!lw && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
@@ -4494,17 +3867,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                                    w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
                 return;
             }
-            if (upd_bound) {
-                hipLaunchKernelGGL(ward_update_batch2_kernel<true>, dim3(wx_blocks), dim3(WX_THREADS), wxb_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
-                                   w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st,
-                                   max_size, n, w->rowmin, w->rownn, rf, wba);
-                hipLaunchKernelGGL(ward_newrow_min_kernel, dim3(WB_K), dim3(1024), 0, ctx->stream, n, w->cnew, w->cn_stride, w->rowoff, w->msz, w->mcid, w->Dtri,
-                                   w->st, max_size, rf, w->cand, w->mcol);
-                return;
-            }
-            hipLaunchKernelGGL(ward_update_batch2_kernel<false>, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
+            hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
-                               w->rowmin, w->rownn, rf, wba);
+                               w->rowmin, w->rownn, rf);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -4518,7 +3883,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         };
         finish_b(); // first batch: one pick by the plain lazy selection
         const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : upd_bound ? 4 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -4529,7 +3894,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = lw ? 3 : upd_bound ? 4 : 2;
+            w->graph_lw = lw ? 3 : 2;
             w->graph_E = rf.E;
             w->graph_ceps = rf.ceps;
         }
@@ -4596,33 +3961,24 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         return icl_fail(ctx, ICL_ERR_HIP, "merge loop did not converge: %d of %lld merges after the step budget (engine bug, not a property of the input)",
                         hst.t, (long long)T);
     const int64_t nmerge = hst.t;
+#ifdef ICL_WARD_TIMERS
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] batched ward: merges %d steps %d commits %d single-pick steps %d general-path steps %d\n", hst.t, hst.B.steps, hst.B.commits,
                 hst.B.slow, hst.B.general);
     if (batched && getenv("ICL_WARD_STATS") && rf.E)
         fprintf(stderr, "[icl] distance bounds in the merge loop: %llu scans of singleton rows, %llu collecting passes, %llu evaluation rounds, %llu entries evaluated\n",
                 hst.B.rf_stat[0], hst.B.rf_stat[1], hst.B.rf_stat[2], hst.B.rf_stat[3]);
-    if (batched && getenv("ICL_WARD_STATS") && rf.upd)
-        fprintf(stderr, "[icl] scans of merged clusters' rows: %llu with a nearest-neighbour list, %llu answered by it; %llu without a list\n", hst.B.rf_stat[8], hst.B.rf_stat[9], hst.B.rf_stat[10]);
     if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] rows of new clusters: %s\n", rf.upd ? "lower bounds from the matrix cores + exact minima (bound body)" : lw ? "Lance-Williams" : "exact values (vector ALUs)");
+        fprintf(stderr, "[icl] rows of new clusters: %s\n", lw ? "Lance-Williams" : "exact values (vector ALUs)");
     if (batched && getenv("ICL_WARD_STATS") && rf.E)
         fprintf(stderr, "[icl] distance bounds, initial row minima: %llu rows, %llu evaluation rounds, %llu entries evaluated (%.2f %% of the pairs)\n",
                 hst.B.rf_stat[4], hst.B.rf_stat[6], hst.B.rf_stat[7], 100.0 * (double)hst.B.rf_stat[7] / (0.5 * (double)n * (double)(n - 1)));
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] non-express finishes: truncated %d, preselection stale/empty %d, new-row-first/forwarding %d; preselection re-minimised %d rows whose partner had died; %.1f rows per step depended on the batch\n", hst.B.why[0], hst.B.why[1], hst.B.why[2], hst.B.why[3], (double)hst.B.sum_dep / (hst.B.steps ? hst.B.steps : 1));
-#ifdef ICL_WARD_TIMERS
-    if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] bound body, per step us: first main start -> last main end %.1f; last main end -> finish start %.1f; preselection start -> first main start %.1f\n",
-                hst.B.dbg4[0] * 0.01 / hst.B.steps, hst.B.dbg4[1] * 0.01 / hst.B.steps, (double)(long long)hst.B.dbg4[2] * 0.01 / hst.B.steps);
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] preselection start -> last spare workgroup's end, per step us: %.1f (phase A done at %.1f); spare rescans: %llu singleton rows, %.1f us each; %llu merged rows, %.1f us each; longest %.1f us\n",
                 hst.B.dbg5[1] * 0.01 / hst.B.steps, hst.B.dbg6[1] * 0.01 / hst.B.steps, hst.B.dbg6[3], hst.B.dbg6[2] * 0.01 / (hst.B.dbg6[3] ? hst.B.dbg6[3] : 1),
                 hst.B.dbg6[5], hst.B.dbg6[4] * 0.01 / (hst.B.dbg6[5] ? hst.B.dbg6[5] : 1), hst.B.dbg6[6] * 0.01);
-    if (batched && getenv("ICL_WARD_STATS"))
-        fprintf(stderr, "[icl] new-row minima, row 0, per step us: list filtered %.1f, done %.1f; bound body, first main workgroup: %.2f blocks per step, stage loop %.1f us, epilogue %.1f us per block\n",
-                hst.B.dbg2[1] * 0.01 / hst.B.steps, hst.B.dbg2[2] * 0.01 / hst.B.steps, (double)hst.B.dbg3[2] / hst.B.steps,
-                hst.B.dbg3[0] * 0.01 / (hst.B.dbg3[2] ? hst.B.dbg3[2] : 1), hst.B.dbg3[1] * 0.01 / (hst.B.dbg3[2] ? hst.B.dbg3[2] : 1));
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
                 hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,

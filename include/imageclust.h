@@ -85,7 +85,10 @@ int icl_embed_file(icl_ctx *ctx, const char *path, int head, float *out);
 /* icl_embed_file is what GetImageEmbedding(appCtx, path) binds to, and workflow.go:156-175 calls that from one goroutine per
  * image.  Concurrent callers are coalesced: each decodes / resizes its own file, then one forward pass serves everything
  * that queued up within window_us (or max_batch images).  prec selects ICL_PREC_FP32 (default: rows equal the one-at-a-time
- * result bit for bit) or ICL_PREC_BF16.  window_us = 0 disables waiting (a lone caller runs at once). */
+ * result bit for bit) or ICL_PREC_BF16.  window_us = 0 disables waiting (a lone caller runs at once).
+ * prec | ICL_FILE_FAIL_NEXT_LEADER: the next batch leader fails with ICL_ERR_NOMEM right after it has taken its queued requests --
+ * every caller of that batch gets the error, nobody is left waiting (the recovery path of the queue, exercised by the test suite). */
+enum { ICL_FILE_FAIL_NEXT_LEADER = 0x100 };
 int icl_set_file_options(icl_ctx *ctx, int prec, int window_us, int max_batch);
 int icl_file_batch_stats(icl_ctx *ctx, int64_t *batches, int64_t *images); /* forward passes run / images served by icl_embed_file */
 /* Image ingest on the host (embeddings.go:50-82): decode a file (baseline or progressive Huffman JPEG, PNG, or binary PPM) to interleaved RGB.
@@ -205,13 +208,11 @@ int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int
                           float *d_E, int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters);
 /* How the exact mode builds ComputeInitialDistanceMatrix (clustering.go:61-73).  ICL_DIST_EXACT: every value by the exact
  * vector-ALU kernel (3 D unfused fp32 ops per pair).  ICL_DIST_BOUND: proven lower bounds from an f32 GEMM on the matrix cores,
- * each entry evaluated exactly (the reference's own expression) only when a row scan finds it near the row's minimum -- the same
- * cluster ids, member order, merge log and merge values, bit for bit.  ICL_DIST_BOUND_INIT: bounds in the initial matrix,
- * UpdateDistanceMatrix's new rows (clustering.go:75-108) as values from the exact vector-ALU kernel.  ICL_DIST_BOUND: the new rows
- * as bounds too (16 new clusters x 16 live clusters per matrix-core instruction), their minima by exact evaluation of the entries
- * in the minimum's band -- the update kernel becomes HBM-bound, but the exact minima and the row re-scans it leaves behind cost more
- * than it saves at N = 100 000 .. 250 000, so it runs on request only.  ICL_DIST_AUTO (default): ICL_DIST_BOUND_INIT
- * for n >= 4096, ICL_DIST_EXACT below. */
+ * made exact on demand -- the reference's own sequential fp32 expression -- by the row scans of the merge loop; the same
+ * cluster ids, member order, merge log and merge values, bit for bit.  UpdateDistanceMatrix's new rows (clustering.go:75-108) are
+ * always values from the exact vector-ALU kernel (round 3 also offered them as bounds: parity-green, slower, retired; the
+ * old name ICL_DIST_BOUND_INIT stays as an alias of ICL_DIST_BOUND).  ICL_DIST_AUTO (default): ICL_DIST_BOUND for n >= 4096,
+ * ICL_DIST_EXACT below. */
 enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3 };
 int icl_set_ward_options(icl_ctx *ctx, int dist_mode);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position

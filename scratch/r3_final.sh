@@ -10,8 +10,6 @@ run bench_n250000 --total-images 250000 --steps 2 --no-cpu-baseline
 run bench_embed_1m --embed-only --total-images 1000000 --steps 1 --no-cpu-baseline
 run bench_n100000_fp32 --prec fp32 --no-cpu-baseline
 run ab_dist_exact --ward-dist exact --steps 2 --no-cpu-baseline
-run ab_dist_bound --ward-dist bound --steps 2 --no-cpu-baseline
-run ab_dist_cut --ward-dist cut --steps 2 --no-cpu-baseline
 run ab_overlap --overlap --steps 2 --no-cpu-baseline
 bash scratch/layers_ab.sh 1 > $O/layers.log 2>&1; cp gpurun_out/layers_mode1.txt $O/embed_layers.txt
 cat $O/steps.log

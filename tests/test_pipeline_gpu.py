@@ -150,16 +150,13 @@ def test_batch_leader_failure_releases_every_caller(ctx, L, tmp_path):
         except L.ICLError as e:
             res[i] = e.code
 
-    os.environ["ICL_TEST_LEADER_THROW"] = "1"
-    try:
-        th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(16)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join(60)
-        assert not any(t.is_alive() for t in th), "a caller is still blocked behind a failed leader"
-    finally:
-        del os.environ["ICL_TEST_LEADER_THROW"]
+    ctx.set_file_options(L.PREC_FP32 | L.FILE_FAIL_NEXT_LEADER, 20000, 64)  # the next leader gives up right after taking its requests
+    th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert not any(t.is_alive() for t in th), "a caller is still blocked behind a failed leader"
     assert all(r == L.ICL_ERR_NOMEM for r in res), res
     want = ctx.embed_u8(np.stack([L.load_image_224(p) for p in paths[:2]]), L.HEAD_DENSE0, L.PREC_FP32)
     ctx.set_file_options(L.PREC_FP32, 500000, 256)  # a lone caller must not wait for this half-second window: nobody else is inside

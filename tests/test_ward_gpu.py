@@ -208,14 +208,11 @@ def test_cluster_all_identical_points(ctx):
     same_as_oracle(ctx, np.ones((37, 5), np.float32), 2, 4)
 
 
-@pytest.mark.parametrize("mode", [2, 3])
-def test_adversarial_batches_with_distance_bounds(ctx, mode):
-    """The inputs aimed at the batched loop again, with distance bounds forced (auto mode only uses them from n = 4096): mode 3 =
-    bounds in the initial matrix, mode 2 = also in the rows of the clusters being created (candidate lists, exact minima from
-    the lists, nearest-neighbour lists; D = 4096 fills the update kernel's LDS to 158.7 KB).  Rolled-back batches, new clusters
-    that are each other's nearest neighbours (virtual-slot entries below every listed one), heavy ties (candidate lists overflow
-    into the full-scan path), targets reached inside a batch, identical points, NaN / Inf."""
-    ctx.set_ward_options(mode)
+def test_adversarial_batches_with_distance_bounds(ctx):
+    """The inputs aimed at the batched loop again, with distance bounds in the initial matrix forced (ICL_DIST_BOUND; auto mode only
+    uses them from n = 4096): rolled-back batches, new clusters that are each other's nearest neighbours, heavy ties (bands that
+    overflow into the full refinement loop), targets reached inside a batch, identical points, NaN / Inf, D = 4096 and D % 4 != 0."""
+    ctx.set_ward_options(2)
     try:
         test_batch_dependent_chain(ctx)
         test_batch_new_clusters_merge_with_each_other(ctx)
@@ -301,7 +298,7 @@ def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
     E1 = (cen[rng.integers(0, 300, 6000)] * (1 + 1e-6 * rng.standard_normal((6000, 1)))).astype(np.float32)
     for E, mn, mx in [(E1, 5, 50), (WC.ties(5000, 5, 9, levels=6), 2, 30)]:
         res = []
-        for mode in (1, 2, 3):  # exact everywhere / bounds in the initial matrix and the new rows / in the initial matrix only
+        for mode in (1, 2):  # every initial distance by the exact kernel / bounds in the initial matrix
             ctx.set_ward_options(mode)
             cid, rank, nc = ctx.cluster(E, mn, mx)
             res.append((cid.copy(), rank.copy(), nc, ctx.last_merges().copy(), ctx.last_merge_values().copy()))
@@ -318,14 +315,6 @@ def test_large_n_creation_ids_past_40960(ctx):
     log and every merge value must equal the oracle's."""
     f = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
     assert f["merges"] == 21360 and 24000 + f["merges"] > 40960
-    # the same run with the new clusters' rows as lower bounds from the matrix cores (ICL_DIST_BOUND: candidate lists, exact minima by
-    # ward_newrow_min_kernel, nearest-neighbour lists of the merged rows): same ids, member order, merge log and values
-    ctx.set_ward_options(2)
-    try:
-        g = same_as_fast_oracle(ctx, WC.mog(24000, 16, 1), 5, 50)
-    finally:
-        ctx.set_ward_options(0)
-    assert g["merges"] == 21360
 
 
 def test_large_n_creation_ids_past_65536(ctx):
@@ -353,6 +342,15 @@ def test_large_n_wide_rows_workgroups_run_several_blocks(ctx):
     the path for the first ~9 000 merges, against the oracle: ids, member order, merge log, every merge value."""
     f = same_as_fast_oracle(ctx, WC.mog(26000, 1024, 5), 5, 50)
     assert f["merges"] == 26000 - O.calc_optimal_clusters(26000, 5, 50)[0]
+
+
+def test_benchmark_regime_d2048_n20000_against_the_oracle(ctx):
+    """The benchmark's regime pinned to the CPU restatement once: D = 2048 (16 ring stages of 32 k-groups per 64-cluster block,
+    the express finish path) and N = 20 000 (313 blocks for 256 persistent workgroups: workgroups run several blocks; distance
+    bounds in the initial matrix, n >= 4096) against ward_fast.c: cluster ids, member order, the merge log and EVERY merge value
+    (clustering.go:198-284).  17 800 merges; the oracle takes about a minute on the box's cores."""
+    f = same_as_fast_oracle(ctx, WC.mog(20000, 2048, 7), 5, 50)
+    assert f["merges"] == 20000 - O.calc_optimal_clusters(20000, 5, 50)[0]
 
 
 def test_config2_full_size_properties_100k(ctx):
@@ -399,12 +397,6 @@ def test_config2_full_size_two_pipelines_agree_100k(ctx):
 
     args = (100000, 2048, 20250218, 5, 50)
     mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
-    ctx.set_ward_options(2)  # ... and a third one: the new clusters' rows as lower bounds from the matrix cores (ICL_DIST_BOUND)
-    try:
-        bound = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
-    finally:
-        ctx.set_ward_options(0)
-    assert bound == mine
     env = dict(os.environ, ICL_WARD_BATCH="0", ICL_CHILD_DIST="1")  # the witness also builds every initial distance with the exact kernel
     p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), *map(str, args)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
