@@ -135,6 +135,7 @@ struct icl_ward_ws {
     int32_t *rownn = nullptr;  // [M]
     int64_t *rowoff = nullptr; // [M+1] float offset in Dtri of the row storage of creation id r (singletons: r * ld; merged clusters: set when picked)
     int32_t *mcol = nullptr;   // [M] column of creation id r (singletons: r; merged clusters: inherited from parent a at commit)
+    uint32_t *mpk = nullptr;   // [ld] by column: (mcid << bits(max_size)) | msz, the row scans' one-word view of msz + mcid
     int32_t *msz = nullptr;    // [ld] by column: size of the occupant if alive else 0
     int32_t *mcid = nullptr;   // [ld] by column: creation id of the occupant
     float *Dtri = nullptr;     // (N + WB_K) rows x ld floats
@@ -168,7 +169,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mpk};
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -442,8 +443,12 @@ __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t 
 // block_argmin): smallest value, then smallest creation id -- the reference's first strict minimum in ascending column order
 // (clustering.go:123-131).  bi is a CREATION ID (-1: none).  Rows start 16-byte aligned; msz / mcid hold ld >= len entries.
 __device__ __forceinline__ int64_t ward_row_len(int64_t r, int64_t n) { return r < n ? r : n; } // singleton r: partners are the singletons below it; merged clusters: any column
+// mpk (may be null): size and creation id of every column in ONE word, (mcid << szb) | msz with szb = the bits of max_size -- a scan
+// then reads 8 instead of 12 bytes per column (the host passes it when 2 n + 4 creation ids fit the remaining bits)
+__device__ __forceinline__ int wpk_bits(int max_size) { return 32 - __clz(max_size); }
 __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
-                                           int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi)
+                                           int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi,
+                                           const uint32_t *__restrict__ mpk = nullptr)
 {
     bv = ICL_MAXF;
     bi = -1;
@@ -458,6 +463,30 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
         }
     };
     const int64_t nvec = len >> 2;
+    if (mpk) {
+        const int szb = wpk_bits(max_size);
+        const uint32_t smask = (1u << szb) - 1u;
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+            float4 v[WB_SCAN_U];
+            uint4 k[WB_SCAN_U];
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const bool has = q < nvec;
+                v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                k[j] = has ? reinterpret_cast<const uint4 *>(mpk)[q] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                visit(v[j].x, (int)(k[j].x & smask), (int)(k[j].x >> szb));
+                visit(v[j].y, (int)(k[j].y & smask), (int)(k[j].y >> szb));
+                visit(v[j].z, (int)(k[j].z & smask), (int)(k[j].z >> szb));
+                visit(v[j].w, (int)(k[j].w & smask), (int)(k[j].w >> szb));
+            }
+        }
+        for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) visit(row[q], (int)(mpk[q] & smask), (int)(mpk[q] >> szb));
+        return;
+    }
     for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
         float4 v[WB_SCAN_U];
         int4 m[WB_SCAN_U], c[WB_SCAN_U];
@@ -656,9 +685,35 @@ __device__ __forceinline__ float ward_scale(float s, int sx, int sy)
 
 // visits columns [0, len) of a row: f(value, msz, mcid, column) with 4 x 16-byte loads of each stream in flight per lane
 template <typename F>
-__device__ __forceinline__ void ward_row_visit(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid, F &&f)
+__device__ __forceinline__ void ward_row_visit(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid, F &&f,
+                                               const uint32_t *__restrict__ mpk = nullptr, int max_size = 1)
 {
     const int64_t nvec = len >> 2;
+    if (mpk) { // sizes and creation ids from one packed stream (scan_row_m)
+        const int szb = wpk_bits(max_size);
+        const uint32_t smask = (1u << szb) - 1u;
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+            float4 v[WB_SCAN_U];
+            uint4 k[WB_SCAN_U];
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const bool has = q < nvec;
+                v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                k[j] = has ? reinterpret_cast<const uint4 *>(mpk)[q] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
+                f(v[j].x, (int)(k[j].x & smask), (int)(k[j].x >> szb), col);
+                f(v[j].y, (int)(k[j].y & smask), (int)(k[j].y >> szb), col + 1);
+                f(v[j].z, (int)(k[j].z & smask), (int)(k[j].z >> szb), col + 2);
+                f(v[j].w, (int)(k[j].w & smask), (int)(k[j].w >> szb), col + 3);
+            }
+        }
+        for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) f(row[q], (int)(mpk[q] & smask), (int)(mpk[q] >> szb), (int)q);
+        return;
+    }
     for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
         float4 v[WB_SCAN_U];
         int4 m[WB_SCAN_U], c[WB_SCAN_U];
@@ -910,10 +965,10 @@ __device__ __forceinline__ void block_argmin2b(float &v0, int &i0, float &v1, in
 // more than WB_REF_CAP of them: its full loop).
 __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine &rf, float *scr)
+                                             const wrefine &rf, float *scr, const uint32_t *__restrict__ mpk = nullptr)
 {
     if (!(rf.E && my_id < rf.n)) { // only singleton rows ever hold bounds
-        scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi);
+        scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, mpk);
         block_argmin(bv, bi, sv, si);
         return;
     }
@@ -942,7 +997,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
                 ti = c;
             }
         }
-    });
+    }, mpk, max_size);
     block_argmin2b(tv, ti, lv, lc, lv2, sv, si);
     if (lc < 0 || lv > tv) { // no bound at or below the best value
         bv = tv;
@@ -1061,7 +1116,7 @@ __global__ __launch_bounds__(1024) void select_dense_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------------------
 __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, int32_t *slot_id, int32_t *id_slot, int32_t *asz,
                                  float *rowmin, int32_t *rownn, int64_t *rowoff, int32_t *mcol, int32_t *msz, int32_t *mcid,
-                                 ward_state *st, int32_t target)
+                                 ward_state *st, int32_t target, uint32_t *mpk, int szb)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < S) slot_id[i] = i < n ? (int32_t)i : -1;
@@ -1076,6 +1131,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
     if (i < ld) {
         msz[i] = i < n ? 1 : 0;
         mcid[i] = i < n ? (int32_t)i : 0x7fffffff;
+        if (mpk) mpk[i] = i < n ? (((uint32_t)i << szb) | 1u) : 0u;
     }
     if (i == 0) {
         st->done = 0;
@@ -1666,7 +1722,7 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                  const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
-                                 int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine &rf)
+                                 int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine &rf, const uint32_t *__restrict__ mpk = nullptr)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ int lcnt;
@@ -1773,7 +1829,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         int ri = -1;
         if (r >= 0) {
             WB_TIMER(const unsigned long long tr0 = wall_clock64();)
-            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf, sv + 1024);
+            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf, sv + 1024, mpk);
             WB_TIMER(if (threadIdx.x == 0) {
                 const unsigned long long dt = wall_clock64() - tr0;
                 atomicAdd(&st->B.dbg6[r < n ? 2 : 4], dt);   /* time in rescans: singleton rows / merged rows */
@@ -1796,7 +1852,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
 __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                      float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                      const int32_t *__restrict__ mcid, int max_size,
-                                     ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine &rf)
+                                     ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine &rf, const uint32_t *__restrict__ mpk = nullptr)
 {
     __shared__ int excl[2 * WB_K];
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
@@ -1989,7 +2045,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf, sv + 1024); // ends with a barrier: cmd may be rewritten afterwards
+        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf, sv + 1024, mpk); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
                 if (ri < 0) {
@@ -2234,14 +2290,15 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                                                                       const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                                                       float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
-                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf)
+                                                                      float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf,
+                                                                      const uint32_t *__restrict__ mpk)
 {
     extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf);
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg5[0], wall_clock64());)
         return;
     }
@@ -2251,7 +2308,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         int *sh = si + 16;
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf);
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -2696,7 +2753,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                                                                 int32_t *__restrict__ merges, float *__restrict__ Dtri,
                                                                 int64_t *__restrict__ rowoff, int32_t *__restrict__ mcol, int32_t *__restrict__ msz,
                                                                 int32_t *__restrict__ mcid, int64_t ld, int max_size, ward_state *__restrict__ st, int lw,
-                                                                int32_t *__restrict__ fdrec, const wrefine rf)
+                                                                int32_t *__restrict__ fdrec, const wrefine rf, uint32_t *__restrict__ mpk)
 {
     // fdrec: the express path's data phase runs in ward_finish_data_kernel (several workgroups) from the record written here
     // (nullptr -- FAST mode, or d % 4 != 0 -- never takes the express path's data phase)
@@ -2860,6 +2917,10 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                 msz[ca] = ls.B.sa[j] + ls.B.sb[j];
                 mcid[ca] = c;
                 msz[cb] = 0;
+                if (mpk) { // the packed copy the row scans read (scan_row_m)
+                    mpk[ca] = ((uint32_t)c << wpk_bits(max_size)) | (uint32_t)(ls.B.sa[j] + ls.B.sb[j]);
+                    mpk[cb] = 0u;
+                }
             }
             rowmin[a] = ICL_MAXF;
             rowmin[b] = ICL_MAXF;
@@ -3279,7 +3340,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             int ri;
             {
                 const int noex[1] = {-1};
-                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf, &fin_scr[0][0]);
+                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf, &fin_scr[0][0], mpk);
             }
             if (threadIdx.x == 0) {
                 rowmin[bi] = rv;
@@ -3419,7 +3480,7 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero};
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mpk};
         w->nrm = nullptr;
         w->colsum = nullptr;
         w->zero = nullptr;
@@ -3466,6 +3527,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         WS_ALLOC(colsum, double, dd);
         WS_ALLOC(zero, char, 256);
         ICL_HIP(ctx, hipMemsetAsync(w->zero, 0, 256, ctx->stream));
+        w->mpk = nullptr;
+        WS_ALLOC(mpk, uint32_t, w->ld);
         WS_ALLOC(msz, int32_t, w->ld);
         WS_ALLOC(mcid, int32_t, w->ld);
         WS_ALLOC(Dtri, float, w->dtri_floats);
@@ -3717,6 +3780,9 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     if (n == 0) return ICL_OK;
     ICL_TRY(ward_ensure(ctx, n, d));
     icl_ward_ws *w = ctx->ward;
+    // the row scans read size + creation id of a column as ONE word when 2 n + 4 creation ids fit beside the bits of max_size
+    const int pk_bits = max_size >= 1 ? 32 - __builtin_clz((unsigned)max_size) : 32;
+    uint32_t *mpk = (pk_bits < 32 && (uint64_t)(2 * n + 4) <= (1ull << (32 - pk_bits))) ? w->mpk : nullptr;
     // every early return below (ICL_HIP / ICL_TRY / icl_fail) releases these through the guards' destructors
     struct ev_guard {
         hipEvent_t e = nullptr;
@@ -3735,7 +3801,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     {
         const int64_t cnt = std::max(std::max(w->S, w->M), w->ld);
         hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, ctx->stream, n, w->S, w->M, w->ld,
-                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)T);
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)T, mpk, pk_bits);
         if (d > 0) {
             hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)icl_ceil_div(w->S, 32), (unsigned)icl_ceil_div((d + 3) / 4, 32)), dim3(256), 0,
                                ctx->stream, d_E, n, d, w->S, w->CT);
@@ -3853,7 +3919,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         auto finish_b = [&]() {
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, w->mcol, w->msz, w->mcid, w->ld, max_size,
-                               w->st, lw ? 1 : 0, fdrec, rf);
+                               w->st, lw ? 1 : 0, fdrec, rf, mpk);
             if (fdrec) // the express step's data phase on several CUs, the pair-interleaved copy of the new centroids, the block counter reset
                 hipLaunchKernelGGL(ward_finish_data_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, WB_FD_THREADS)), dim3(WB_FD_THREADS), 0,
                                    ctx->stream, d, w->S, w->CT, w->Crow, w->cnew, w->cnewI, w->cn_stride, fdrec, w->st);
@@ -3869,7 +3935,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
             hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
-                               w->rowmin, w->rownn, rf);
+                               w->rowmin, w->rownn, rf, mpk);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -4193,7 +4259,7 @@ extern "C" int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t
     {
         const int64_t cnt = std::max(std::max(w->S, w->M), w->ld);
         hipLaunchKernelGGL(ward_init_kernel, dim3((unsigned)icl_ceil_div(cnt, 256)), dim3(256), 0, s3, n, w->S, w->M, w->ld,
-                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)0);
+                           w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid, w->st, (int32_t)0, (uint32_t *)nullptr, 0);
     }
     int64_t next_tr = 0;
     const int64_t ntr = icl_ceil_div(n, DT_TILE);
