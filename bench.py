@@ -324,13 +324,13 @@ def main():
         traffic = traffic_upd = pmc_file = None
         traffic_note = ""
         # the PMC means were taken at the default workload (100 000 images, bf16): quoted for that workload only
-        for cand in ("r03_pmc_traffic.json", "r02c_pmc_traffic.json"):  # scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script)
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # scratch/collect_profiles.sh (rocprofv3 --pmc passes of THIS script)
             if n_total != 100000 or args.prec != "bf16":
                 break
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     pmc = json.load(f)
-                convs = [v for k, v in pmc.items() if k.startswith("conv_igemm_kernel<BF16, 128") or k.startswith("conv3x3_halo_kernel<BF16, 128")]
+                convs = [v for k, v in pmc.items() if k.startswith("conv_igemm_kernel<BF16, 128") or k.startswith("conv3x3_halo_kernel<BF16, 128") or k.startswith("bneck56_kernel")]
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in convs) / max(sum(v["launches"] for v in convs), 1), 0)
                 upd_pmc = [v for k, v in pmc.items() if k.startswith("ward_update_batch2_kernel")]  # (a template since round 3: "...<false>" is the exact body)
                 traffic_upd = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in upd_pmc) / max(sum(v["launches"] for v in upd_pmc), 1), 0)

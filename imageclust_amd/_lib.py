@@ -18,6 +18,7 @@ PREC_FP32, PREC_BF16 = 0, 1
 UPDATE_EXACT, UPDATE_LW = 0, 1
 SYNTH_NOISE, SYNTH_STRUCTURED = 0, 1
 TILES_AUTO, TILES_LOCAL, TILES_DISTRIBUTED = 0, 1, 2
+MERGE_GPU0, MERGE_SHARDED = 0, 1
 FILE_FAIL_NEXT_LEADER = 0x100
 K_CONV, K_DIST_EXACT, K_DIST_MFMA, K_ROWMIN, K_UPDATE, K_EMBED_OTHER, K_CONV64 = range(7)
 K_NAMES = ["conv_igemm_kernel<*,128>", "ward_dist_exact_kernel", "dist_mfma_kernel", "row_argmin_*_kernel",
@@ -84,7 +85,7 @@ SYMBOLS = [
     ("icl_ward_distance_rows_dev", _int, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     ("icl_ward_prepare", _int, [_vp, _i64, _i32]),
     ("icl_ward_unpack_spans_dev", _int, [_vp, _i32, _pi64, _pi64, C.POINTER(_vp)]),
-    ("icl_group_set_options", _int, [_vp, _int]),
+    ("icl_group_set_options", _int, [_vp, _int, _int]),
     ("icl_cluster_prefilled_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _i64, _i64, _vp, _vp, _pi32]),
     ("icl_cluster", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
     ("icl_cluster_dev", _int, [_vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _pi32]),
@@ -461,9 +462,10 @@ class Group:
             self.L.icl_group_destroy(self.g)
             self.g = _vp()
 
-    def set_options(self, tiles_mode=0):
-        """Who builds the initial distance matrix: TILES_AUTO (GPU 0 alone below 6 GPUs), TILES_LOCAL, TILES_DISTRIBUTED."""
-        self._check(self.L.icl_group_set_options(self.g, tiles_mode))
+    def set_options(self, tiles_mode=0, merge_mode=0):
+        """Who builds the initial distance matrix: TILES_AUTO (GPU 0 alone below 6 GPUs), TILES_LOCAL, TILES_DISTRIBUTED; where the
+        merge loop runs: MERGE_GPU0, MERGE_SHARDED (every GPU a replica of the state, the new rows' blocks dealt out)."""
+        self._check(self.L.icl_group_set_options(self.g, tiles_mode, merge_mode))
 
     def size(self):
         return self.L.icl_group_size(self.g)
@@ -489,6 +491,17 @@ class Group:
         nc = _i32()
         self._check(self.L.icl_group_cluster(self.g, E.ctypes.data, n, d, min_size, max_size, update, cid.ctypes.data, rank.ctypes.data, C.byref(nc)))
         return cid[:n], rank[:n], nc.value
+
+    def last_merges(self, i=0):
+        """Merge log (creation ids) / Ward values of the last cluster call, from the context of GPU i (icl_group_ctx)."""
+        h = self.L.icl_group_ctx(self.g, i)
+        n = self.L.icl_last_merges(h, None, 0)
+        m = np.zeros((max(n, 1), 2), np.int32)
+        self.L.icl_last_merges(h, m.ctypes.data, n)
+        k = self.L.icl_last_merge_values(h, None, 0)
+        v = np.zeros(max(k, 1), np.float32)
+        self.L.icl_last_merge_values(h, v.ctypes.data, k)
+        return m[:n], v[:k]
 
     def embed_cluster(self, imgs, min_size, max_size, prec=PREC_BF16, update=UPDATE_EXACT, want_E=True):
         """workflow.go:84-94 in one call: embed (2048-d pooled) on all GPUs, E assembled on the devices, clustered on GPU 0.

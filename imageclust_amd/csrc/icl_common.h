@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -28,6 +29,40 @@ struct icl_pending_event {
 struct icl_model;  // resnet.hip
 struct icl_ward_ws; // ward.hip
 
+// Strip-sharded merge loop (ward.hip "replicated state, sharded blocks"; multi_gpu.hip): what the G replicas of one group call share.
+#define ICL_SHARD_MAX 16
+struct icl_ward_shard {
+    int G = 0;
+    const float *D[ICL_SHARD_MAX] = {};   // replica r's distance matrix, published once its workspace exists
+    hipEvent_t ev[ICL_SHARD_MAX][2] = {}; // replica r's "update launch of this step is complete" (two alternate)
+    // host barrier over the G driving threads; a replica that fails releases the others
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long gen = 0;
+    bool failed = false;
+    bool wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const long long my = gen;
+        if (++arrived == G) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return gen != my || failed; });
+        return !failed;
+    }
+    void fail()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
 struct icl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -53,6 +88,8 @@ struct icl_ctx {
     // subsystems
     icl_model *model = nullptr;
     icl_ward_ws *ward = nullptr;
+    icl_ward_shard *shard = nullptr; // set by the group around a sharded cluster call: this context is replica shard_rank of shard->G
+    int shard_rank = 0;
     int64_t *ward_rowoff = nullptr; // row offsets of the packed triangle for ranks that only compute distance rows (ward.hip)
     int64_t ward_rowoff_n = 0;
     void *file_batcher = nullptr; // icl_embed_file's coalescing queue (resnet.hip)

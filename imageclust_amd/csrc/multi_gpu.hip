@@ -16,6 +16,7 @@
 // icl_cluster_prefilled_dev) with RCCL send/recv as the transport.
 #include "icl_common.h"
 
+#include <cstring>
 #include <new>
 #include <thread>
 
@@ -23,6 +24,7 @@ struct icl_group {
     std::vector<icl_ctx *> ctx;
     std::vector<char> peer0; // GPU 0 can read context i's device memory directly (same device, or peer access enabled)
     int tiles_mode = ICL_TILES_AUTO;
+    int merge_mode = ICL_MERGE_GPU0;
     std::string err;
     std::mutex mu;
 };
@@ -108,11 +110,14 @@ extern "C" void icl_group_destroy(icl_group *g)
     delete g;
 }
 
-extern "C" int icl_group_set_options(icl_group *g, int tiles_mode)
+extern "C" int icl_group_set_options(icl_group *g, int tiles_mode, int merge_mode)
 {
-    if (!g || tiles_mode < ICL_TILES_AUTO || tiles_mode > ICL_TILES_DISTRIBUTED) return group_fail(g, ICL_ERR_ARG, "icl_group_set_options: bad argument");
+    if (!g || tiles_mode < ICL_TILES_AUTO || tiles_mode > ICL_TILES_DISTRIBUTED || merge_mode < ICL_MERGE_GPU0 || merge_mode > ICL_MERGE_SHARDED)
+        return group_fail(g, ICL_ERR_ARG, "icl_group_set_options: bad argument");
+    if (merge_mode == ICL_MERGE_SHARDED && (int)g->ctx.size() > ICL_SHARD_MAX) return group_fail(g, ICL_ERR_UNSUPPORTED, "the sharded merge loop takes at most 16 GPUs");
     std::lock_guard<std::mutex> lk(g->mu);
     g->tiles_mode = tiles_mode;
+    g->merge_mode = merge_mode;
     return ICL_OK;
 }
 extern "C" int32_t icl_group_size(icl_group *g) { return g ? (int32_t)g->ctx.size() : 0; }
@@ -189,16 +194,63 @@ extern "C" int icl_group_embed_u8(icl_group *g, const uint8_t *hwc_rgb, int64_t 
 // area-balanced runs into buffers of their own memory; GPU 0 then reads those spans over xGMI straight into its matrix rows
 // (all peers concurrently, one link each) -- or, for a device that is no peer, through a bounded landing buffer --, computes
 // its own run from bounds and runs the exact merge loop.  Nothing is staged on GPU 0.
-static bool group_deals_rows(icl_group *g)
+static bool group_shards_merges(icl_group *g) { return g->ctx.size() > 1 && g->merge_mode == ICL_MERGE_SHARDED; }
+static bool group_deals_rows(icl_group *g) // (also: every GPU needs all of E)
 {
     const int parts = (int)g->ctx.size();
-    return parts > 1 && (g->tiles_mode == ICL_TILES_DISTRIBUTED || (g->tiles_mode == ICL_TILES_AUTO && parts >= ICL_GROUP_DIST_MIN));
+    return parts > 1 && (group_shards_merges(g) || g->tiles_mode == ICL_TILES_DISTRIBUTED || (g->tiles_mode == ICL_TILES_AUTO && parts >= ICL_GROUP_DIST_MIN));
+}
+// The strip-sharded exact merge loop (ward.hip, "replicated state, sharded blocks"): every GPU runs the WHOLE clustering call on its
+// own replica of the state -- its own distance matrix (4 n^2 bytes fit every 288 GB GPU up to configs[4]'s 250 000), built locally from
+// the matrix-core bounds -- but its update launches compute only the 64-cluster blocks b == rank (mod G) of the rows being created;
+// after each update launch the replicas pull the other blocks' entries out of each other's matrices (peer-mapped memory over xGMI,
+// one event wait per peer and step) and finish the step identically.  The per-step vector arithmetic divides by G, the exchange is
+// <= 16 rows x n_live x 4 bytes x (G-1)/G per GPU.  Replica 0's outputs are returned; all replicas compute the same ones.
+static int group_cluster_sharded(icl_group *g, const std::vector<float *> &dE, int64_t n, int32_t d, int32_t min_size, int32_t max_size,
+                                 int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
+{
+    const int parts = (int)g->ctx.size();
+    icl_ward_shard sh;
+    sh.G = parts;
+    int rc = ICL_OK;
+    for (int i = 0; i < parts && rc == ICL_OK; ++i) {
+        icl_device_guard dg(g->ctx[(size_t)i]->device);
+        for (int k = 0; k < 2 && rc == ICL_OK; ++k)
+            if (hipEventCreateWithFlags(&sh.ev[i][k], hipEventDisableTiming) != hipSuccess) rc = group_fail(g, ICL_ERR_HIP, "sharded merge loop: event creation failed");
+    }
+    std::vector<std::vector<int32_t>> scratch((size_t)parts);
+    std::vector<int32_t> ncl((size_t)parts, 0);
+    if (rc == ICL_OK) {
+        for (int i = 1; i < parts; ++i) scratch[(size_t)i].assign((size_t)(2 * n), 0);
+        for (int i = 0; i < parts; ++i) {
+            g->ctx[(size_t)i]->shard = &sh;
+            g->ctx[(size_t)i]->shard_rank = i;
+        }
+        rc = for_each_ctx(g, [&](int i, icl_ctx *c) -> int {
+            int32_t *cid = i == 0 ? cluster_id : scratch[(size_t)i].data(), *mr = i == 0 ? member_rank : scratch[(size_t)i].data() + n;
+            return icl_cluster_dev(c, dE[(size_t)i], n, d, min_size, max_size, ICL_UPDATE_EXACT, cid, mr, &ncl[(size_t)i]);
+        });
+        for (int i = 0; i < parts; ++i) g->ctx[(size_t)i]->shard = nullptr;
+        if (rc == ICL_OK) {
+            *n_clusters = ncl[0];
+            for (int i = 1; i < parts; ++i) // the replicas ran the same loop on the same data
+                if (ncl[(size_t)i] != ncl[0] || memcmp(scratch[(size_t)i].data(), cluster_id, (size_t)n * 4) != 0)
+                    rc = group_fail(g, ICL_ERR_HIP, "sharded merge loop: replica " + std::to_string(i) + " disagrees with replica 0 (engine bug)");
+        }
+    }
+    for (int i = 0; i < parts; ++i) {
+        icl_device_guard dg(g->ctx[(size_t)i]->device);
+        for (int k = 0; k < 2; ++k)
+            if (sh.ev[i][k]) (void)hipEventDestroy(sh.ev[i][k]);
+    }
+    return rc;
 }
 static int group_cluster_resident(icl_group *g, const std::vector<float *> &dE, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                                   int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters)
 {
     const int parts = (int)g->ctx.size();
     icl_ctx *c0 = g->ctx[0];
+    if (group_shards_merges(g) && update == ICL_UPDATE_EXACT) return group_cluster_sharded(g, dE, n, d, min_size, max_size, cluster_id, member_rank, n_clusters);
     if (!group_deals_rows(g)) {
         const int rc = icl_cluster_dev(c0, dE[0], n, d, min_size, max_size, update, cluster_id, member_rank, n_clusters);
         return rc == ICL_OK ? rc : group_fail(g, rc, icl_last_error(c0));

@@ -2291,8 +2291,11 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
                                                                       float *__restrict__ Dtri,
                                                                       ward_state *__restrict__ st, int max_size, int64_t n,
                                                                       float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf,
-                                                                      const uint32_t *__restrict__ mpk)
+                                                                      const uint32_t *__restrict__ mpk, int sh_rank, int sh_n)
 {
+    // sh_rank / sh_n: strip-sharded loop (several replicas of the whole state, one per GPU): this replica's main workgroups take the
+    // 64-cluster blocks b == sh_rank (mod sh_n); the other blocks' entries of the new rows are pulled from their owners afterwards
+    // (ward_pull_rows_kernel).  One GPU: 0 / 1.
     extern __shared__ __attribute__((aligned(16))) float4 wb_lds[]; // ring [WX_R][WX_STAGE_F4] float4
     // grid: [0, WB_R) spare row re-minimisers, WB_R the preselection, WB_R+1 the virtual slots, then the persistent main workgroups
     if (blockIdx.x < WB_R) {
@@ -2349,7 +2352,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         if (pf_done < 2 && upto >= 2) { // the drawn block's clusters; which of its columns are stale
             int r = pf_raw;
             asm volatile("" : "+v"(r)); // the atomic's result is first looked at HERE (hipcc otherwise hoists the readfirstlane, and with it the wait, next to the atomic)
-            pf_blk = __builtin_amdgcn_readfirstlane(r);
+            pf_blk = sh_rank + sh_n * __builtin_amdgcn_readfirstlane(r); // (the counter and the workgroup index number this replica's blocks)
             const bool on = (int64_t)pf_blk * 64 < nlive;
             const int sl = pf_blk * 64 + lane;
             pf_dirty = 0;
@@ -2585,6 +2588,65 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
     } // block loop
+}
+
+// Strip-sharded loop, after the update launch of a step: the entries of the rows being created that OTHER replicas' main
+// workgroups computed (blocks b != rank mod G) are read out of the owners' matrices -- peer-mapped memory: the reads cross xGMI --
+// into this replica's rows, with the addressing and the validity rules of the update kernel's epilogue, and enter the rows' keys
+// (ckey: the row's first minimum at its cluster's time, ckey2: over the clusters that survive the whole batch) exactly as if they
+// had been computed here.  One wave per 64-cluster block.  Every replica then holds the same rows and keys and runs the same finish step.
+struct ward_peers {
+    const float *D[ICL_SHARD_MAX];
+};
+__global__ __launch_bounds__(64) void ward_pull_rows_kernel(const ward_peers pe, int G, int rank, float *__restrict__ Dtri,
+                                                           const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                           const int32_t *__restrict__ mcol, const int64_t *__restrict__ rowoff,
+                                                           ward_state *__restrict__ st, int max_size, int64_t n)
+{
+    const int lane = threadIdx.x;
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    if (done || nb <= 0) return;
+    __shared__ int pa[WB_K], pb[WB_K], psc[WB_K];
+    __shared__ int64_t ro_l[WB_K];
+    if (lane < WB_K) {
+        pa[lane] = st->B.a[lane];
+        pb[lane] = st->B.b[lane];
+        psc[lane] = st->B.sa[lane] + st->B.sb[lane];
+        ro_l[lane] = lane < nb ? rowoff[n + t + lane] : 0;
+    }
+    __syncthreads();
+    for (int64_t blk = blockIdx.x; blk * 64 < nlive; blk += gridDim.x) {
+        const int owner = (int)(blk % G);
+        if (owner == rank) continue;
+        const float *__restrict__ Dp = pe.D[owner];
+        const int64_t sl = blk * 64 + lane;
+        const int x = sl < nlive ? slot_id[sl] : -1;
+        const int sx = x >= 0 ? asz[x] : 0, mx = x >= 0 ? mcol[x] : 0;
+        unsigned okmask = 0;
+        bool alive = x >= 0 && sx > 0;
+#pragma unroll
+        for (int j = 0; j < WB_K; ++j)
+            if (j < nb) {
+                alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+                if (alive && sx + psc[j] <= max_size) okmask |= 1u << j;
+            }
+        const bool survives = alive;
+        for (int j = 0; j < nb; ++j) {
+            unsigned long long key = ~0ull, key2 = ~0ull;
+            if ((okmask >> j) & 1u) {
+                const float val = Dp[ro_l[j] + mx];
+                Dtri[ro_l[j] + mx] = val;
+                if (val < ICL_MAXF) {
+                    key = ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)x;
+                    if (survives) key2 = key;
+                }
+            }
+            key = wave_umin64(key);
+            key2 = wave_umin64(key2);
+            if (lane == 0 && key != ~0ull) atomicMin(&st->B.ckey[j], key);
+            if (lane == 0 && key2 != ~0ull) atomicMin(&st->B.ckey2[j], key2);
+        }
+    }
 }
 
 // FAST mode (ICL_UPDATE_LW) on the batched loop: the rows of the tentative clusters by the Lance-Williams recurrence
@@ -3778,6 +3840,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     *n_clusters = 0;
     const int64_t T = n - k; // merges needed for len(clusters) == k (clustering.go:220)
     if (n == 0) return ICL_OK;
+    // a replica of a sharded group call that leaves early releases the replicas waiting for it (icl_ward_shard::wait)
+    struct shard_guard {
+        icl_ward_shard *s;
+        bool ok = false;
+        ~shard_guard() { if (s && !ok) s->fail(); }
+    } shg{ctx->shard};
     ICL_TRY(ward_ensure(ctx, n, d));
     icl_ward_ws *w = ctx->ward;
     // the row scans read size + creation id of a column as ONE word when 2 n + 4 creation ids fit beside the bits of max_size
@@ -3908,8 +3976,11 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         const int dqb = (int)wb_groups(d);
         const unsigned lw_blocks_b = (unsigned)icl_ceil_div(w->S, WB_THREADS) + 2 + WB_R;
         const size_t wx_lds_bytes = (size_t)WX_R * WX_STAGE_F4 * 16;
+        // strip-sharded loop (a group's replicas, multi_gpu.hip): this replica's main workgroups take the blocks == sh_rank (mod sh_n)
+        icl_ward_shard *sh = lw ? nullptr : ctx->shard;
+        const int sh_n = sh ? sh->G : 1, sh_rank = sh ? ctx->shard_rank : 0;
         // main workgroups: persistent, at most one per CU (they draw blocks from a counter); fewer when the input has fewer blocks
-        const unsigned wx_blocks = (unsigned)std::min<int64_t>(w->S / 64, (int64_t)ctx->prop.multiProcessorCount) + 2 + WB_R;
+        const unsigned wx_blocks = (unsigned)std::min<int64_t>(icl_ceil_div(w->S / 64, sh_n), (int64_t)ctx->prop.multiProcessorCount) + 2 + WB_R;
         if (!w->wx_attr) { // per context, i.e. per device: a group drives one context per GPU
             ICL_HIP(ctx, hipFuncSetAttribute((const void *)ward_update_batch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wx_lds_bytes)); // + ~7 KB of static arrays of the spare / preselection roles
             w->wx_attr = true;
@@ -3935,7 +4006,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             }
             hipLaunchKernelGGL(ward_update_batch2_kernel, dim3(wx_blocks), dim3(WX_THREADS), wx_lds_bytes, ctx->stream, d, dqb, w->S, w->CT, w->Crow,
                                w->cnew, w->cnewI, w->cn_stride, w->slot_id, w->id_slot, w->asz, w->rowoff, w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n,
-                               w->rowmin, w->rownn, rf, mpk);
+                               w->rowmin, w->rownn, rf, mpk, sh_rank, sh_n);
         };
         auto step_b = [&](bool prof) {
             if (prof) {
@@ -3948,7 +4019,28 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             finish_b();
         };
         finish_b(); // first batch: one pick by the plain lazy selection
-        const bool use_graph = !prof_update && T >= 2 * GRAPH_STEPS;
+        ward_peers peers{};
+        if (sh) { // every replica's matrix is known to every replica before the first pull
+            sh->D[sh_rank] = w->Dtri;
+            if (!sh->wait()) return icl_fail(ctx, ICL_ERR_HIP, "sharded merge loop: another replica failed");
+            for (int r = 0; r < sh_n; ++r) peers.D[r] = sh->D[r];
+        }
+        int64_t sh_step = 0;
+        // one step of the sharded loop: update (own blocks) -> every replica's update is complete -> pull the other blocks' entries -> finish
+        auto step_sharded = [&]() -> bool {
+            update_b();
+            hipEvent_t mine = sh->ev[sh_rank][sh_step & 1];
+            if (hipEventRecord(mine, ctx->stream) != hipSuccess) return false;
+            if (!sh->wait()) return false; // (host side: every replica has recorded its event before anybody waits on it)
+            for (int r = 0; r < sh_n; ++r)
+                if (r != sh_rank && hipStreamWaitEvent(ctx->stream, sh->ev[r][sh_step & 1], 0) != hipSuccess) return false;
+            hipLaunchKernelGGL(ward_pull_rows_kernel, dim3((unsigned)std::min<int64_t>(w->S / 64, 2048)), dim3(64), 0, ctx->stream, peers, sh_n, sh_rank, w->Dtri,
+                               w->slot_id, w->asz, w->mcol, w->rowoff, w->st, max_size, n);
+            finish_b();
+            ++sh_step;
+            return true;
+        };
+        const bool use_graph = !sh && !prof_update && T >= 2 * GRAPH_STEPS;
         if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
@@ -3977,6 +4069,10 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         while (!fin && chunk < max_chunks) {
             if (use_graph) {
                 if (hipGraphLaunch(w->graph_exec, ctx->stream) != hipSuccess) { rc_b = ICL_ERR_HIP; break; }
+            } else if (sh) {
+                bool ok_s = true;
+                for (int g = 0; g < GRAPH_STEPS && ok_s; ++g) ok_s = step_sharded();
+                if (!ok_s) { rc_b = ICL_ERR_HIP; break; }
             } else {
                 for (int g = 0; g < GRAPH_STEPS; ++g) step_b(prof_update);
             }
@@ -4082,6 +4178,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     ctx->last_dist_ms = ms01;
     ctx->last_merge_ms = ms12;
     icl_prof_collect(ctx);
+    shg.ok = true; // the merge loop is over: nobody waits for this replica any more
     int rc = assign_ids(ctx, n, min_size, max_size, pairs, nmerge, cluster_id, member_rank, n_clusters);
     ctx->last_merges.swap(pairs);
     return rc;

@@ -155,7 +155,13 @@ int icl_group_embed_cluster(icl_group *g, const uint8_t *hwc_rgb, int64_t n, int
  * from matrix-core bounds below 6 GPUs (one GPU fills the matrix faster than its peers' exact rows arrive over one xGMI link
  * each) and deals the rows out from 6 GPUs on; ICL_TILES_LOCAL / ICL_TILES_DISTRIBUTED force either.  Results do not depend on it. */
 enum { ICL_TILES_AUTO = 0, ICL_TILES_LOCAL = 1, ICL_TILES_DISTRIBUTED = 2 };
-int icl_group_set_options(icl_group *g, int tiles_mode);
+/* Where the exact merge loop (clustering.go:220-246) runs.  ICL_MERGE_GPU0 (default): on GPU 0.  ICL_MERGE_SHARDED: on every GPU at
+ * once -- each holds a replica of the whole state (its own 4 n^2-byte distance matrix) and computes only every G-th 64-cluster
+ * block of UpdateDistanceMatrix's new rows (clustering.go:76-96); after each update launch the replicas read the other blocks'
+ * entries out of each other's matrices (peer access over xGMI) and finish the step identically.  The per-step vector arithmetic
+ * divides by the number of GPUs; cluster ids, member order and merge log stay bit-identical.  At most 16 GPUs. */
+enum { ICL_MERGE_GPU0 = 0, ICL_MERGE_SHARDED = 1 };
+int icl_group_set_options(icl_group *g, int tiles_mode, int merge_mode);
 
 /* The building blocks of the above, for callers that bring their own transport (bench.py: one process per GPU, RCCL
  * send/recv).  TRANSPORT FORMAT of distance rows: rows [row_lo, row_hi) of the packed lower triangle (row r = r floats, padded

@@ -236,3 +236,29 @@ def test_group_keeps_only_the_matrix_on_gpu0(L):
             ctx.close()
     f = O.cluster_fast(E, 5, 50, lazy_ban=False)
     assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"])
+
+
+def test_sharded_merge_loop_equals_the_oracle(L):
+    """ICL_MERGE_SHARDED (the multi-GPU form of configs[4]): three replicas of the whole state (three contexts
+    on this box's one device), each computing every third 64-cluster block of UpdateDistanceMatrix's new rows (clustering.go:76-96)
+    and pulling the other blocks' entries out of the other replicas' matrices after every update launch.  N = 24 000 (375 blocks,
+    21 360 merges, creation ids past 40 960): cluster ids, member order, the merge log and every merge value of EVERY replica against
+    ward_fast.c, plus a wide-row case (D = 2048) and small / ragged cases that exercise partly filled blocks and batches that roll back."""
+    g = L.Group([0, 0, 0])
+    try:
+        g.set_options(L.TILES_AUTO, L.MERGE_SHARDED)
+        for (E, mn, mx) in [(WC.mog(24000, 16, 1), 5, 50), (WC.mog(3000, 2048, 4), 3, 6), (WC.ties(1100, 4, 2, levels=5), 2, 9), (WC.quadruples(seed=5, groups=250), 1, 1000),
+                            (WC.quadruples(seed=6, groups=200), 2, 4), (WC.mog(900, 6, 9), 1, 9), (WC.mog(700, 6, 9), 1, 9)]:
+            f = O.cluster_fast(E, mn, mx, lazy_ban=False)
+            cid, rank, nc = g.cluster(E, mn, mx)
+            assert nc == f["n_clusters"] and np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"]), E.shape
+            for i in range(3):
+                m, v = g.last_merges(i)
+                assert np.array_equal(m, f["log"][:, 2:4].astype(np.int32)), (E.shape, i)
+                assert np.array_equal(v.view(np.uint32), f["vals"].view(np.uint32)), (E.shape, i)
+        # inputs too small to deal out and the FAST mode take the single-GPU path
+        cid, rank, nc = g.cluster(WC.mog(64, 8, 1), 3, 6)
+        r = O.cluster(WC.mog(64, 8, 1), 3, 6)
+        assert np.array_equal(cid, r["cluster_id"]) and nc == r["n_clusters"]
+    finally:
+        g.close()
