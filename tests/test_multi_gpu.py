@@ -252,7 +252,7 @@ def test_sharded_merge_loop_equals_the_oracle(L):
             f = O.cluster_fast(E, mn, mx, lazy_ban=False)
             cid, rank, nc = g.cluster(E, mn, mx)
             assert nc == f["n_clusters"] and np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"]), E.shape
-            for i in range(3):
+            for i in range(3 if len(E) >= 2 * 128 * 3 else 1):  # (inputs too small to deal out run on GPU 0 alone)
                 m, v = g.last_merges(i)
                 assert np.array_equal(m, f["log"][:, 2:4].astype(np.int32)), (E.shape, i)
                 assert np.array_equal(v.view(np.uint32), f["vals"].view(np.uint32)), (E.shape, i)
