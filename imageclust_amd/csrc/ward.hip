@@ -69,6 +69,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WB_RM 2 /* rows each of them takes (matches wg, wg + WB_R, ...); the rest stays lazy.  Round 3 (a re-scan now reads three streams and the spare
                    workgroups hold 50 CUs while they run): 48 x 2 -> merge loop 1 370 ms at N=100k, 48 x 4 1 391, 64 x 2 1 400, 64 x 3 1 409, 32 x 4 1 470 */
 #endif
+// Waiting on a flag another workgroup publishes: the polls are RELAXED agent-scope loads and ONE acquire fence follows the wait.  An acquire
+// load per poll costs a `buffer_inv sc1` each time -- on this part that invalidates the XCD's L2 lines of ordinary memory, under the feet
+// of the row scans running on the same XCD (measured: a 100 000-column re-scan 73 us in this kernel, 20 us alone on the GPU).
+__device__ __forceinline__ int wb_poll(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wb_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 #define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 96 are re-minimised per step; the rest stays lazy) */
 #define WB_WTOP 5    /* keys a wave / a slice reports before its sentinel */
 #define WB_PA_KEYS (WB_WTOP + 1)
@@ -464,8 +469,24 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
     };
     const int64_t nvec = len >> 2;
     if (mpk) {
+        // Keys instead of branches (round 4): values of a plain row are >= +0, so (value bits << 32 | creation id) orders like (value, id).
+        // A group of 4 x WB_SCAN_U columns is reduced with selects only; the exclusion list is consulted ONCE per group, and only when
+        // the group's best beats the thread's (with a branch per column and the 32-entry list behind it the loop was bound by
+        // instruction issue: 73 us per 100 000 columns against 20 us for the loads alone, scratch/rowscan_bench.hip).
         const int szb = wpk_bits(max_size);
         const uint32_t smask = (1u << szb) - 1u;
+        const unsigned long long none = (unsigned long long)__float_as_uint(ICL_MAXF) << 32; // nothing below MaxFloat32
+        unsigned long long best = none;
+        auto key_of = [&](float v, uint32_t k) -> unsigned long long {
+            const int m = (int)(k & smask), c = (int)(k >> szb);
+            const bool ok = (m > 0) & (m + my_size <= max_size) & (c < my_id);
+            return ((unsigned long long)(ok ? __float_as_uint(v) : 0xffffffffu) << 32) | (unsigned)c;
+        };
+        auto is_ex = [&](int c) {
+            bool hit = false;
+            for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
+            return hit;
+        };
         for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
             float4 v[WB_SCAN_U];
             uint4 k[WB_SCAN_U];
@@ -476,15 +497,40 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
                 v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
                 k[j] = has ? reinterpret_cast<const uint4 *>(mpk)[q] : make_uint4(0, 0, 0, 0);
             }
+            unsigned long long g = ~0ull;
 #pragma unroll
             for (int j = 0; j < WB_SCAN_U; ++j) {
-                visit(v[j].x, (int)(k[j].x & smask), (int)(k[j].x >> szb));
-                visit(v[j].y, (int)(k[j].y & smask), (int)(k[j].y >> szb));
-                visit(v[j].z, (int)(k[j].z & smask), (int)(k[j].z >> szb));
-                visit(v[j].w, (int)(k[j].w & smask), (int)(k[j].w >> szb));
+                unsigned long long e;
+                e = key_of(v[j].x, k[j].x); g = e < g ? e : g;
+                e = key_of(v[j].y, k[j].y); g = e < g ? e : g;
+                e = key_of(v[j].z, k[j].z); g = e < g ? e : g;
+                e = key_of(v[j].w, k[j].w); g = e < g ? e : g;
+            }
+            if (g < best) { // rare after the first groups
+                if (!is_ex((int)(unsigned)(g & 0xffffffffull)))
+                    best = g;
+                else { // the group's head is a member of the batch: its other columns one by one
+#pragma unroll
+                    for (int j = 0; j < WB_SCAN_U; ++j) {
+                        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                        const uint32_t kk[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const unsigned long long e = key_of(vv[e4], kk[e4]);
+                            if (e < best && !is_ex((int)(unsigned)(e & 0xffffffffull))) best = e;
+                        }
+                    }
+                }
             }
         }
-        for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) visit(row[q], (int)(mpk[q] & smask), (int)(mpk[q] >> szb));
+        for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) {
+            const unsigned long long e = key_of(row[q], mpk[q]);
+            if (e < best && !is_ex((int)(unsigned)(e & 0xffffffffull))) best = e;
+        }
+        if (best < none) {
+            bv = __uint_as_float((uint32_t)(best >> 32));
+            bi = (int)(unsigned)(best & 0xffffffffull);
+        }
         return;
     }
     for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
@@ -956,6 +1002,9 @@ __device__ __forceinline__ void block_argmin2b(float &v0, int &i0, float &v1, in
     __syncthreads(); // the scratch may be rewritten
 }
 
+#ifdef ICL_WARD_TIMERS
+__device__ unsigned long long g_scan_dbg[8]; // plain row scans: [0] time in the load/visit loop, [1] in the reduce, [2] scans, [3] columns
+#endif
 // The row scan of every merge-loop kernel: result reduced over the workgroup.
 // Rows that may hold bounds (singleton rows while rf.E is set): ONE pass finds the first minimum among VALUES and the smallest
 // lower bound among flagged entries.  If the best value is strictly below every bound, every flagged entry's true value is
@@ -968,8 +1017,16 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
                                              const wrefine &rf, float *scr, const uint32_t *__restrict__ mpk = nullptr)
 {
     if (!(rf.E && my_id < rf.n)) { // only singleton rows ever hold bounds
+        WB_TIMER(const unsigned long long ts0 = wall_clock64();)
         scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, mpk);
+        WB_TIMER(const unsigned long long ts1 = wall_clock64();)
         block_argmin(bv, bi, sv, si);
+        WB_TIMER(if (threadIdx.x == 0 && gridDim.x > 1) {
+            atomicAdd(&g_scan_dbg[0], ts1 - ts0);
+            atomicAdd(&g_scan_dbg[1], wall_clock64() - ts1);
+            atomicAdd(&g_scan_dbg[2], 1ull);
+            atomicAdd(&g_scan_dbg[3], (unsigned long long)len);
+        })
         return;
     }
     auto excluded = [&](int c) {
@@ -979,6 +1036,110 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
     };
     float tv = ICL_MAXF, lv = ICL_MAXF, lv2 = ICL_MAXF; // lv2: the second smallest lower bound (an excluded entry may count: it only errs low)
     int ti = -1, lc = -1;
+    if (mpk) {
+        // the same pass on keys (see scan_row_m): values (value bits << 32 | creation id), bounds (|entry| bits << 32 | column); a group of
+        // 4 x WB_SCAN_U columns is reduced with selects only and the exclusion list is consulted once per group, when its head beats the thread's
+        const int szb = wpk_bits(max_size);
+        const uint32_t smask = (1u << szb) - 1u;
+        const unsigned long long none = (unsigned long long)__float_as_uint(ICL_MAXF) << 32;
+        unsigned long long tbest = none, l1 = none;
+        uint32_t l2 = __float_as_uint(ICL_MAXF);
+        const int64_t nvec = len >> 2;
+        auto slow = [&](float v, uint32_t k, int col) { // one column, the rules spelled out (tail columns; groups whose head is a member of the batch)
+            const int m = (int)(k & smask), c = (int)(k >> szb);
+            if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
+            const uint32_t vb = __float_as_uint(v);
+            if (vb >> 31) {
+                const uint32_t Lb = vb & 0x7fffffffu;
+                const unsigned long long bk = ((unsigned long long)Lb << 32) | (unsigned)col;
+                if (bk < l1) {
+                    if (!excluded(c)) {
+                        const uint32_t o = (uint32_t)(l1 >> 32);
+                        l2 = o < l2 ? o : l2;
+                        l1 = bk;
+                    }
+                } else
+                    l2 = Lb < l2 ? Lb : l2;
+            } else {
+                const unsigned long long vk = ((unsigned long long)vb << 32) | (unsigned)c;
+                if (vk < tbest && !excluded(c)) tbest = vk;
+            }
+        };
+        for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+            float4 v[WB_SCAN_U];
+            uint4 k[WB_SCAN_U];
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                const int64_t q = q0 + (int64_t)j * blockDim.x;
+                const bool has = q < nvec;
+                v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                k[j] = has ? reinterpret_cast<const uint4 *>(mpk)[q] : make_uint4(0, 0, 0, 0);
+            }
+            unsigned long long gv = ~0ull, g1 = ~0ull;
+            uint32_t g2 = 0xffffffffu;
+            auto one = [&](float vf, uint32_t kw, int col) {
+                const int m = (int)(kw & smask), c = (int)(kw >> szb);
+                const bool ok = (m > 0) & (m + my_size <= max_size) & (c < my_id);
+                const uint32_t vb = __float_as_uint(vf);
+                const bool fl = (vb >> 31) != 0;
+                const unsigned long long vk = ((unsigned long long)((ok & !fl) ? vb : 0xffffffffu) << 32) | (unsigned)c;
+                gv = vk < gv ? vk : gv;
+                const uint32_t Lb = (ok & fl) ? (vb & 0x7fffffffu) : 0xffffffffu;
+                const uint32_t h1 = (uint32_t)(g1 >> 32);
+                const uint32_t mx = h1 > Lb ? h1 : Lb;
+                g2 = mx < g2 ? mx : g2;
+                const unsigned long long bk = ((unsigned long long)Lb << 32) | (unsigned)col;
+                g1 = bk < g1 ? bk : g1;
+            };
+#pragma unroll
+            for (int j = 0; j < WB_SCAN_U; ++j) {
+                const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
+                one(v[j].x, k[j].x, col);
+                one(v[j].y, k[j].y, col + 1);
+                one(v[j].z, k[j].z, col + 2);
+                one(v[j].w, k[j].w, col + 3);
+            }
+            bool redo = false;
+            if (gv < tbest) {
+                if (!excluded((int)(unsigned)(gv & 0xffffffffull)))
+                    tbest = gv;
+                else
+                    redo = true;
+            }
+            if (g1 < l1) {
+                const int c1 = (int)(mpk[(unsigned)(g1 & 0xffffffffull)] >> szb);
+                if (excluded(c1)) redo = true;
+            }
+            if (redo) { // (tbest may already hold this group's value head: the column-by-column pass finds nothing smaller among its values)
+#pragma unroll
+                for (int j = 0; j < WB_SCAN_U; ++j) {
+                    const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
+                    slow(v[j].x, k[j].x, col);
+                    slow(v[j].y, k[j].y, col + 1);
+                    slow(v[j].z, k[j].z, col + 2);
+                    slow(v[j].w, k[j].w, col + 3);
+                }
+            } else {
+                const uint32_t h = (uint32_t)(g1 >> 32), o = (uint32_t)(l1 >> 32);
+                if (g1 < l1) {
+                    l2 = o < l2 ? o : l2;
+                    l2 = g2 < l2 ? g2 : l2;
+                    l1 = g1;
+                } else
+                    l2 = h < l2 ? h : l2; // (the group's second bound is no smaller)
+            }
+        }
+        for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x) slow(row[q], mpk[q], (int)q);
+        if (tbest < none) {
+            tv = __uint_as_float((uint32_t)(tbest >> 32));
+            ti = (int)(unsigned)(tbest & 0xffffffffull);
+        }
+        if (l1 < none) {
+            lv = __uint_as_float((uint32_t)(l1 >> 32));
+            lc = (int)(unsigned)(l1 & 0xffffffffull);
+        }
+        lv2 = __uint_as_float(l2 < __float_as_uint(ICL_MAXF) ? l2 : __float_as_uint(ICL_MAXF));
+    } else
     ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
         if (!(m > 0 && m + my_size <= max_size && c < my_id)) return;
         if (wflagged(v)) {
@@ -997,7 +1158,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
                 ti = c;
             }
         }
-    }, mpk, max_size);
+    });
     block_argmin2b(tv, ti, lv, lc, lv2, sv, si);
     if (lc < 0 || lv > tv) { // no bound at or below the best value
         bv = tv;
@@ -1798,9 +1959,10 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         // ---- barrier over the WB_R spare workgroups (all resident: they are the first workgroups of the grid)
         int ok = lane >= WB_R;
         for (int spin = 0; spin < 200000 && !__all(ok); ++spin) {
-            if (!ok) ok = __hip_atomic_load(&st->B.pa_flag[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+            if (!ok) ok = wb_poll(&st->B.pa_flag[lane < WB_R ? lane : 0]) == epoch;
             if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
         }
+        wb_acquire();
         // ---- phase B assignment: global index of a matched row = matches of earlier slices + its position
         int cnt_l = (lane < WB_R && ok) ? __hip_atomic_load(&st->B.pa_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         if (!__all(ok)) cnt_l = 0; // a slice is missing (cannot happen on a healthy device): nothing speculative this step
@@ -1882,9 +2044,10 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
     if (wave == 0) {
         int ok = lane >= WB_R;
         for (int spin = 0; spin < 200000 && !__all(ok); ++spin) {
-            if (!ok) ok = __hip_atomic_load(&st->B.pa_flag[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch0;
+            if (!ok) ok = wb_poll(&st->B.pa_flag[lane < WB_R ? lane : 0]) == epoch0;
             if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
         }
+        wb_acquire();
         if (lane == 0) cmd[3] = __all(ok) ? 1 : 0;
     }
     __syncthreads();
@@ -1967,9 +2130,10 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                     if (spl_n < 0) { // the spare workgroups' results (they run ahead of this workgroup in the grid)
                         int ok = lane >= WB_R;
                         for (int spin = 0; spin < 20000 && !ok; ++spin) {
-                            ok = __hip_atomic_load(&st->B.spec_done[lane < WB_R ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                            ok = wb_poll(&st->B.spec_done[lane < WB_R ? lane : 0]) == epoch;
                             if (!ok) __builtin_amdgcn_s_sleep(4);
                         }
+                        wb_acquire();
                         spl_n = __all(ok) ? WB_R : 0;
                         if (spl_n && lane < WB_R) {
 #pragma unroll
@@ -2318,6 +2482,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WB_TIMER(const unsigned long long tm0 = wall_clock64();)
+    WB_TIMER(if (threadIdx.x == 0 && blockIdx.x > WB_R + 1) atomicMin(&st->B.dbg4[3], tm0);) // first main start
     const bool virt = blockIdx.x == WB_R + 1; // "virtual slots": lane i = tentative cluster c_i, column = its new centroid
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     if (done || nb <= 0) return;
@@ -2588,6 +2753,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         WB_TIMER(if (lane == 0 && j == 0 && virt) st->B.dbg[2] += wall_clock64() - tm0;)
     }
     } // block loop
+    WB_TIMER(if (threadIdx.x == 0 && !virt) atomicMax(&st->B.dbg3[3], wall_clock64());) // last main end
 }
 
 // Strip-sharded loop, after the update launch of a step: the entries of the rows being created that OTHER replicas' main
@@ -3850,7 +4016,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     icl_ward_ws *w = ctx->ward;
     // the row scans read size + creation id of a column as ONE word when 2 n + 4 creation ids fit beside the bits of max_size
     const int pk_bits = max_size >= 1 ? 32 - __builtin_clz((unsigned)max_size) : 32;
-    uint32_t *mpk = (pk_bits < 32 && (uint64_t)(2 * n + 4) <= (1ull << (32 - pk_bits))) ? w->mpk : nullptr;
+    // (not in FAST mode: the packed scans compare (value bits, id) keys, which needs values >= +0 -- exact Ward values are, the MFMA estimates need not be)
+    uint32_t *mpk = (!lw && pk_bits < 32 && (uint64_t)(2 * n + 4) <= (1ull << (32 - pk_bits))) ? w->mpk : nullptr;
     // every early return below (ICL_HIP / ICL_TRY / icl_fail) releases these through the guards' destructors
     struct ev_guard {
         hipEvent_t e = nullptr;
@@ -4141,6 +4308,15 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         fprintf(stderr, "[icl] preselection start -> last spare workgroup's end, per step us: %.1f (phase A done at %.1f); spare rescans: %llu singleton rows, %.1f us each; %llu merged rows, %.1f us each; longest %.1f us\n",
                 hst.B.dbg5[1] * 0.01 / hst.B.steps, hst.B.dbg6[1] * 0.01 / hst.B.steps, hst.B.dbg6[3], hst.B.dbg6[2] * 0.01 / (hst.B.dbg6[3] ? hst.B.dbg6[3] : 1),
                 hst.B.dbg6[5], hst.B.dbg6[4] * 0.01 / (hst.B.dbg6[5] ? hst.B.dbg6[5] : 1), hst.B.dbg6[6] * 0.01);
+    if (batched && getenv("ICL_WARD_STATS")) {
+        unsigned long long gs[8] = {0};
+        (void)hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_scan_dbg), sizeof(gs));
+        unsigned long long zero[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), zero, sizeof(zero));
+        fprintf(stderr, "[icl] plain row scans: %llu, %.0f columns each, %.1f us in the load/visit loop, %.1f us in the reduce; per step us: first main start -> last main end %.1f, preselection start -> first main start %.1f, last main end -> finish start %.1f\n",
+                gs[2], (double)gs[3] / (gs[2] ? gs[2] : 1), gs[0] * 0.01 / (gs[2] ? gs[2] : 1), gs[1] * 0.01 / (gs[2] ? gs[2] : 1), hst.B.dbg4[0] * 0.01 / hst.B.steps,
+                hst.B.dbg4[2] * 0.01 / hst.B.steps, hst.B.dbg4[1] * 0.01 / hst.B.steps);
+    }
     if (batched && getenv("ICL_WARD_STATS"))
         fprintf(stderr, "[icl] per step us (100MHz clock): presel %.1f (scan+pop %.1f, rescans/step %.2f) main0 %.1f virt %.1f | finish: commit %.1f select-end %.1f select+copies %.1f total %.1f\n",
                 hst.B.dbg[0] * 0.01 / hst.B.steps, hst.B.dbg[7] * 0.01 / hst.B.steps, (double)hst.B.dbg[6] / hst.B.steps, hst.B.dbg[1] * 0.01 / hst.B.steps, hst.B.dbg[2] * 0.01 / hst.B.steps,

@@ -2,7 +2,7 @@ import csv, sys
 tr=list(csv.DictReader(open(sys.argv[1])))
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name']) for r in tr]
 ev.sort()
-idx=[i for i,e in enumerate(ev) if e[2].startswith("void stem_conv")]
+idx=[i for i,e in enumerate(ev) if "stem" in e[2][:40]]
 a,b=idx[1],idx[2]
 batch=ev[a:b]
 nblocks=[3,4,6,3]
@@ -19,7 +19,16 @@ for s in range(4):
         layers.append(('s%d.b%d.c3'%(s+1,bl),mid + (cin if bl==0 else 0),cout,1,ho))
         cin=cout;h=ho
 convs=[e for e in batch if 'conv_igemm' in e[2] or 'conv3x3_halo' in e[2]]
+fusedb=[e for e in batch if 'bneck56' in e[2]]
 tot=0;totf=0;agg={}
+if fusedb:  # round 4: each stage-1 bottleneck is ONE kernel (c1 -> c2 -> c3 (+ downsample) + residual + ReLU)
+    for bl,(s,e,n) in enumerate(fusedb):
+        blk=[l for l in layers if l[0].startswith('s1.b%d.'%bl)]
+        fl=sum(2*256*ho*ho*co*ci*k*k for (_,ci,co,k,ho) in blk); us=(e-s)/1e3
+        M=256*56*56; byt=(M*(64 if bl==0 else 256)+M*256)*2
+        tot+=us;totf+=fl
+        print("fused stage-1 bottleneck %d (%s)  M=%7d  %8.1f us  %6.1f TF/s  ~%5.2f TB/s (block input read once + output written once)"%(bl,'downsample' if bl==0 else 'identity',M,us,fl/us/1e6,byt/us/1e6))
+    layers=[l for l in layers if not l[0].startswith('s1.')]
 for (s,e,n),(name,ci,co,k,ho) in zip(convs,layers):
     M=256*ho*ho; K=ci*k*k; fl=2*M*co*K; us=(e-s)/1e3
     tot+=us;totf+=fl

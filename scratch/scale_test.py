@@ -43,5 +43,5 @@ if __name__ == "__main__":
             st = ctx.last_stage_ms()
             kept = cid[cid >= 0]; counts = np.bincount(kept)
             m = ctx.last_merges()
-            print(name, "lib", a.lib, "n", n, "time %.2fs" % dt, st, "clusters", nc, "sizes", counts.min(), counts.max(), "merges", len(m),
+            print(name, "lib", a.lib, "n", n, "time %.2fs" % dt, st, "clusters", nc, "sizes", counts.min(), counts.max(), "merges", len(m), "stats(merges,steps,single,sum_live)", ctx.last_ward_stats(),
                   "dropped", int((cid < 0).sum()), "log-crc", int(np.bitwise_xor.reduce(m.astype(np.int64).ravel() * np.arange(1, m.size + 1))), flush=True)
