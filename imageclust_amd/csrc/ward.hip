@@ -74,7 +74,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // of the row scans running on the same XCD (measured: a 100 000-column re-scan 73 us in this kernel, 20 us alone on the GPU).
 __device__ __forceinline__ int wb_poll(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wb_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-#define WB_PA_CAP 16 /* matched rows a slice can publish (WB_R * WB_RM = 96 are re-minimised per step; the rest stays lazy) */
+#define WB_NN_BOUND (-2) /* rownn of a row whose cache is only a LOWER bound of its minimum (lb mode: a row of Lance-Williams bounds that was never scanned) */
+#define WB_PA_CAP 32 /* matched rows a slice can publish (WB_R * WB_RM = 96 are re-minimised per step; the rest stays lazy) */
 #define WB_WTOP 5    /* keys a wave / a slice reports before its sentinel */
 #define WB_PA_KEYS (WB_WTOP + 1)
 struct ward_batch_state {
@@ -121,6 +122,7 @@ struct ward_state {
     float pre_val;
     int32_t pad;
     unsigned long long ckey; // (value bits << 32 | column id) minimum of the new cluster's row, built with atomicMin
+    float lb_g1, lb_delta2;  // lb mode (ward_update_lb_kernel): the constants of ward_lb_value, set by ward_lb_consts_kernel from the data's norms
     ward_batch_state B;      // batched exact mode
 };
 
@@ -574,6 +576,12 @@ struct wrefine {
                       // decides how much is made exact ahead of need.  The initial row minima use a generous margin (the evaluations
                       // of one round run in parallel, one per thread: ~10 us whether 3 or 1000), so that the merge loop's rescans --
                       // which sit on the update kernel's critical path -- find the near entries exact already
+    // rows of MERGED clusters may hold flagged entries too (lb != 0: the new rows are Lance-Williams lower bounds, ward_update_lb_kernel):
+    // where a merged cluster's centroid and size stand during the merge loop
+    const float *Crow = nullptr;      // [slot][d]
+    const int32_t *id_slot = nullptr; // creation id -> slot
+    const int32_t *asz = nullptr;     // creation id -> size
+    int lb = 0;
 };
 __device__ __forceinline__ bool wflagged(float v) { return (__float_as_uint(v) >> 31) != 0; }
 // upper bound of the value behind a flagged entry L of two singletons; ns = nrm[a] + nrm[b]
@@ -727,7 +735,12 @@ __device__ __forceinline__ float ward_scale(float s, int sx, int sy)
     const float den = (float)(sx + sy);                    // :143
     return (num / den) * s;                                // :144
 }
-
+// centroid and size of cluster `id` for an exact evaluation: singletons straight from E, merged clusters (only in rows of lb mode) from Crow
+__device__ __forceinline__ const float *wcent(const wrefine &rf, int id)
+{
+    return id < rf.n ? rf.E + (int64_t)id * rf.d : rf.Crow + (int64_t)rf.id_slot[id] * rf.d;
+}
+__device__ __forceinline__ int wsize(const wrefine &rf, int id) { return id < rf.n ? 1 : rf.asz[id]; }
 
 // visits columns [0, len) of a row: f(value, msz, mcid, column) with 4 x 16-byte loads of each stream in flight per lane
 template <typename F>
@@ -838,7 +851,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
         return hit;
     };
-    const float nme = rf.nrm[my_id];
+    const float nme = my_id < rf.n ? rf.nrm[my_id] : 0.0f;
     for (bool first = true;; first = false) {
         // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
         float tv = first ? tv0 : ICL_MAXF, ub = ICL_MAXF, lmin = first ? 0.0f : ICL_MAXF;
@@ -850,7 +863,8 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
                 const float L = fabsf(v);
                 lmin = L < lmin ? L : lmin; // (an excluded entry counted here only costs an empty pass B)
                 if (L < tv && L < ub) { // its upper bound (>= L) can only matter below this thread's best value and best upper bound
-                    const float up = wupper(L, nme + rf.nrm[c], rf); // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin
+                    // +inf / NaN when norms overflow: never lowers ub, the entry still counts through lmin; no upper bound is kept for pairs with a merged member
+                    const float up = (my_id < rf.n && c < rf.n) ? wupper(L, nme + rf.nrm[c], rf) : ICL_MAXF;
                     if (up < ub && !excluded(c)) ub = up;
                 }
             } else if (v < tv || (v == tv && c < ti)) {
@@ -890,12 +904,12 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         float rv = ICL_MAXF;
         int ri = -1;
         if ((rf.d & 3) == 0 && m <= 3 * (int)(blockDim.x >> 6)) { // a few entries: one per WAVE at a time (ward_sqdist_wave); many: one per thread
-            const float *yc = rf.E + (int64_t)my_id * rf.d;
+            const float *yc = wcent(rf, my_id);
             for (int q = threadIdx.x >> 6; q < m; q += (int)(blockDim.x >> 6)) {
                 const int col = ref_col[q];
                 const int c = mcid[col];
-                const float *xc = rf.E + (int64_t)c * rf.d;
-                const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr + (threadIdx.x >> 6) * 256), 1, 1);
+                const float *xc = wcent(rf, c);
+                const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr + (threadIdx.x >> 6) * 256), wsize(rf, c), my_size);
                 if ((threadIdx.x & 63) == 0) row[col] = val; // a value from now on
                 if (val < rv || (val == rv && c < ri)) {
                     rv = val;
@@ -906,7 +920,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         for (int q = threadIdx.x; q < m; q += blockDim.x) {
             const int col = ref_col[q];
             const int c = mcid[col];
-            const float val = ward_singleton_pair(rf.E, rf.d, my_id, c);
+            const float val = (my_id < rf.n && c < rf.n) ? ward_singleton_pair(rf.E, rf.d, my_id, c) : ward_pair_value(wcent(rf, c), wcent(rf, my_id), rf.d, wsize(rf, c), my_size);
             row[col] = val; // a value from now on
             if (val < rv || (val == rv && c < ri)) {
                 rv = val;
@@ -1016,7 +1030,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
                                              const wrefine &rf, float *scr, const uint32_t *__restrict__ mpk = nullptr)
 {
-    if (!(rf.E && my_id < rf.n)) { // only singleton rows ever hold bounds
+    if (!(rf.E && (my_id < rf.n || rf.lb))) { // only singleton rows ever hold bounds (lb mode: every row may)
         WB_TIMER(const unsigned long long ts0 = wall_clock64();)
         scan_row_m(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, mpk);
         WB_TIMER(const unsigned long long ts1 = wall_clock64();)
@@ -1173,9 +1187,9 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         // collecting pass below.
         const int c = mcid[lc];
         if (threadIdx.x < 64) {
-            const float *yc = rf.E + (int64_t)my_id * rf.d;
-            const float *xc = rf.E + (int64_t)c * rf.d;
-            const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr), 1, 1);
+            const float *yc = wcent(rf, my_id);
+            const float *xc = wcent(rf, c);
+            const float val = ward_scale(ward_sqdist_wave(xc, yc, rf.d, scr), wsize(rf, c), my_size);
             if (threadIdx.x == 0) {
                 row[lc] = val; // a value from now on
                 sv[0] = val;
@@ -1200,7 +1214,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, scr);
         return;
     }
-    const float up = wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf);
+    const float up = (my_id < rf.n && mcid[lc] < rf.n) ? wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf) : ICL_MAXF;
     const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
     scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, scr);
 }
@@ -1924,6 +1938,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
                 self |= r == ex[z];
                 dep |= (nnv[e] >= 0) & (nnv[e] == ex[z]);
             }
+            dep |= nnv[e] == WB_NN_BOUND; // (lb mode) a row that has never been scanned: made exact one step after its creation
             if (self) continue; // the batch's own members are dead if it commits
             if (dep) {
                 const int at = atomicAdd(&lcnt, 1);
@@ -2109,17 +2124,17 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                 const int r = (int)((m & 0xffffffffull) >> 1);
                 const int rn = __shfl(nn, src, 64);
                 const int ralive = __shfl((int)nn_alive, src, 64);
-                if (rn < 0) { // no partner at all: drop
+                if (rn == -1) { // no partner at all: drop
                     if (lane == src) key = ~0ull;
                     continue;
                 }
-                if (!ralive) { // its cached partner has really died: exact rescan, written back
+                if (!ralive && rn != WB_NN_BOUND) { // its cached partner has really died: exact rescan, written back
                     action = 2;
                     arow = r;
                     alane = src;
                     break;
                 }
-                bool in_batch = false, in_picks = false;
+                bool in_batch = rn == WB_NN_BOUND, in_picks = false; // (a bound row: the spare workgroups have re-minimised it without the batch's members, like a row whose partner is in the batch)
 #pragma unroll
                 for (int z = 0; z < 2 * WB_K; ++z) {
                     in_batch |= ex[z] == rn;
@@ -2930,6 +2945,221 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// lb mode (round 4, ICL_DIST_LWBOUND): the rows of new clusters as PROVEN LOWER BOUNDS from the Lance-Williams recurrence.
+//
+// UpdateDistanceMatrix (clustering.go:76-96) recomputes WardDistance(c, x) for the new cluster c = a U b against every live x: 3 D
+// unfused fp32 operations per entry, 16 rows per pass -- the vector-ALU-bound 170 us of every step.  Only the few entries near a
+// row's minimum ever decide anything.  In lb mode the row is filled with lower bounds L(c,x) <= R(c,x) (R: the reference's value),
+// flagged by the sign bit like the bounds of the initial matrix, from 12 bytes of reads per entry; an entry is evaluated exactly -- the
+// reference's own sequential fp32 expression on the two centroids (ward_sqdist_wave on Crow / E) -- by the row scans when its bound
+// reaches the band that could hold the row's minimum (scan_row_min).  Nothing a comparison sees is ever a bound: a pick is always an
+// exact first minimum of a scanned row; a new row enters the caches as (lower bound, WB_NN_BOUND) and is re-minimised by the spare
+// workgroups of the next step; the validation of a batch and the express selection compare pick values with the new rows' LOWER
+// bounds, which errs towards committing fewer picks (they stay in the caches) -- never towards a wrong order.
+//
+// The bound (u = 2^-24; sizes s_a, s_b, s_x; W(p,q) = s_p s_q / (s_p + s_q) |p - q|^2 in real arithmetic on the fp32 centroid vectors
+// the reference holds; g = (1 + u)^(D + 8) - 1):
+//  (i)   R(p,q) = fl(fl(num/den) * s^) with s^ the sequential fp32 sum of fl(fl(p_k - q_k)^2): all terms >= 0, so R lies in
+//        W(p,q) (1 -+ g).  Hence W(a,x) >= L(a,x) / (1 + g) for ANY lower bound L(a,x) <= R(a,x) -- an exact
+//        entry is its own lower bound -- and W(a,b) <= R(a,b) / (1 - g) with R(a,b) the merge's value (picks are exact).
+//  (ii)  Lance-Williams for Ward is an identity of real arithmetic for the exact weighted mean c* = (s_a a + s_b b) / (s_a + s_b):
+//        W(c*,x) = [(s_a + s_x) W(a,x) + (s_b + s_x) W(b,x) - s_x W(a,b)] / (s_a + s_b + s_x)  >=  W_lo, the same expression on the
+//        bounds of (i).
+//  (iii) The reference's centroid is c_k = fl(fl(fl(s_a a_k) + fl(s_b b_k)) / (s_a + s_b)) (clustering.go:37-40):
+//        |c_k - c*_k| <= 4.01 u max(|a_k|, |b_k|), so |c - c*| <= 4.01 sqrt(2) u M =: Delta with M >= the 2-norm of every centroid
+//        (ward_lb_consts_kernel: from the computed norms of the embeddings; merged centroids are convex combinations up to a factor
+//        (1 + 6u) per generation).  |c - x| >= |c* - x| - Delta, so with w = (s_a + s_b) s_x / (s_a + s_b + s_x):
+//        W(c,x) >= w (sqrt(W(c*,x) / w) - Delta)^2 >= W(c*,x) - 2 Delta sqrt(w W(c*,x)), which is increasing in W(c*,x) wherever it
+//        is positive: W_lo may stand in for W(c*,x).
+//  (iv)  R(c,x) >= (1 - g) W(c,x).  The fp32 evaluation below uses g1 = 1.01 g + 16 u and 2.01 Delta, which cover its own roundings
+//        (every product and sum of non-negative terms errs by <= u relative; the one subtraction is rounded relative to its RESULT);
+//        results below 1e-30 (underflow range), not finite, or NaN store L = 0: no claim, the entry is evaluated when it matters.
+// Bounds compound: a row built from bounds holds bounds of bounds, each generation ~3 g lower; entries that matter are made exact by
+// the scans, which resets them.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ward_lb_value(float La, float Lb, float Rab, int sa, int sb, int sx, float g1, float delta2)
+{
+    const float st = (float)(sa + sb + sx);
+    const float p = (float)(sa + sx) * La + (float)(sb + sx) * Lb;
+    const float q = (float)sx * Rab;
+    const float wl = (p * (1.0f - g1) - q * (1.0f + g1)) / st;
+    if (!(wl > 0.0f)) return 0.0f;
+    const float w = (float)((int64_t)(sa + sb) * (int64_t)sx) / st;
+    const float L = wl * (1.0f - g1) - delta2 * sqrtf(w * wl);
+    return (L > 1e-30f && L < 1e37f) ? L : 0.0f;
+}
+__device__ __forceinline__ float wflag(float L) { return __uint_as_float(__float_as_uint(L) | 0x80000000u); }
+
+// M = bound of every centroid's 2-norm from the computed centred norms nrm[i] ~ |E_i - mu|^2 and mu = colsum / n; one workgroup
+__global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__restrict__ nrm, const double *__restrict__ colsum, int64_t n, int d, int max_size,
+                                                              ward_state *__restrict__ st)
+{
+    __shared__ float smax[16];
+    __shared__ double ssum[16];
+    float mx = 0.0f;
+    bool bad = false;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float v = nrm[i];
+        bad |= !(v >= 0.0f && v < 1e37f);
+        mx = v > mx ? v : mx;
+    }
+    double mu2 = 0.0;
+    for (int k = threadIdx.x; k < d; k += 1024) {
+        const double m = colsum[k] / (double)n;
+        mu2 += m * m;
+    }
+    if (bad) mx = __builtin_inff();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_down(mx, off, 64));
+        mu2 += __shfl_down(mu2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smax[threadIdx.x >> 6] = mx;
+        ssum[threadIdx.x >> 6] = mu2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.0f;
+        double sm = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            m = fmaxf(m, smax[w]);
+            sm += ssum[w];
+        }
+        const double u = 5.9604644775390625e-08;
+        const double depth = (double)(max_size < n ? max_size : n);
+        const double M = (sqrt((double)m) + sqrt(sm)) * (1.0 + 6.0 * u * depth) * 1.001;
+        const double g = exp((d + 8) * log1p(u)) - 1.0;
+        st->lb_g1 = (float)((1.01 * g + 16.0 * u) * (1.0 + 1e-6));
+        const double delta = 4.01 * 1.41421356237309515 * u * M;
+        st->lb_delta2 = (float)(2.01 * delta * (1.0 + 1e-6)); // (+inf when a norm overflows: every bound becomes 0 = no claim)
+    }
+}
+
+#define WL_THREADS 768
+// update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
+// the pairs of clusters created by this batch, then one lane per live cluster.
+__global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
+                                                                   const int64_t *__restrict__ rowoff, const int32_t *__restrict__ mcol,
+                                                                   const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
+                                                                   float *__restrict__ Dtri, ward_state *__restrict__ st, int max_size, int64_t n,
+                                                                   float *__restrict__ rowmin, int32_t *__restrict__ rownn, const wrefine rf,
+                                                                   const uint32_t *__restrict__ mpk)
+{
+    __shared__ __attribute__((aligned(16))) float lds[1024 + (WL_THREADS / 64) * 256]; // sv / si / sh, then ward_sqdist_wave's scratch (256 floats per wave)
+    float *sv = lds;
+    int *si = reinterpret_cast<int *>(sv + 16);
+    int *sh = si + 16;
+    if (blockIdx.x < WB_R) {
+        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
+        WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg5[0], wall_clock64());)
+        return;
+    }
+    if (blockIdx.x == WB_R) {
+        WB_TIMER(const unsigned long long t0 = wall_clock64();)
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
+        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
+        WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WB_TIMER(const unsigned long long tm0 = wall_clock64();)
+    WB_TIMER(if (threadIdx.x == 0 && blockIdx.x > WB_R + 1) atomicMin(&st->B.dbg4[3], tm0);)
+    const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
+    if (done || nb <= 0) return;
+    const float g1 = st->lb_g1, delta2 = st->lb_delta2;
+    __shared__ int pa[WB_K], pb[WB_K], psa[WB_K], psb[WB_K], mca[WB_K], mcb[WB_K];
+    __shared__ float pv[WB_K];
+    __shared__ int64_t roa[WB_K], rob[WB_K], ron[WB_K];
+    __shared__ unsigned long long wk[WL_THREADS / 64][WB_K][2];
+    if (threadIdx.x < WB_K) {
+        const int j = threadIdx.x;
+        const bool on = j < nb;
+        const int a = on ? st->B.a[j] : -1, b = on ? st->B.b[j] : -1;
+        pa[j] = a;
+        pb[j] = b;
+        psa[j] = on ? st->B.sa[j] : 0;
+        psb[j] = on ? st->B.sb[j] : 0;
+        pv[j] = on ? st->B.val[j] : 0.0f;
+        mca[j] = on ? mcol[a] : 0;
+        mcb[j] = on ? mcol[b] : 0;
+        roa[j] = on ? rowoff[a] : 0;
+        rob[j] = on ? rowoff[b] : 0;
+        ron[j] = on ? rowoff[n + t + j] : 0;
+    }
+    __syncthreads();
+    // |entry| of the pair (p, x): the pair lives in the row of the larger creation id, at the other's column; a flagged entry is a
+    // lower bound of the value, an unflagged one the value itself
+    if (blockIdx.x == WB_R + 1) {
+        // clusters created by this batch against each other: thread (i, j), i < j < nb, bounds D(c_j, c_i) by nesting the recurrence
+        const int vi = (int)threadIdx.x / WB_K, vj = (int)threadIdx.x % WB_K;
+        if (vi < vj && vj < nb) {
+            const int ai = pa[vi], bi = pb[vi], sai = psa[vi], sbi = psb[vi], aj = pa[vj], bj = pb[vj];
+            const int sci = sai + sbi, scj = psa[vj] + psb[vj];
+            if (sci + scj <= max_size) {
+                const float l_ai_aj = fabsf(tri_at(Dtri, rowoff, mcol, ai, aj)), l_bi_aj = fabsf(tri_at(Dtri, rowoff, mcol, bi, aj));
+                const float l_ai_bj = fabsf(tri_at(Dtri, rowoff, mcol, ai, bj)), l_bi_bj = fabsf(tri_at(Dtri, rowoff, mcol, bi, bj));
+                const float l_ci_aj = ward_lb_value(l_ai_aj, l_bi_aj, pv[vi], sai, sbi, psa[vj], g1, delta2);
+                const float l_ci_bj = ward_lb_value(l_ai_bj, l_bi_bj, pv[vi], sai, sbi, psb[vj], g1, delta2);
+                const float v = ward_lb_value(l_ci_aj, l_ci_bj, pv[vj], psa[vj], psb[vj], sci, g1, delta2);
+                Dtri[ron[vj] + mca[vi]] = wflag(v); // c_i takes over a_i's column when it commits
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(n + t + vi);
+                atomicMin(&st->B.ckey[vj], key);
+                atomicMin(&st->B.ckey2[vj], key); // a cluster created by this batch survives it
+            }
+        }
+        return;
+    }
+    const int64_t slot0 = ((int64_t)blockIdx.x - (WB_R + 2)) * WL_THREADS;
+    if (slot0 >= nlive) return;
+    const int64_t slot = slot0 + threadIdx.x;
+    const int x = slot < nlive && slot < S ? slot_id[slot] : -1;
+    const int sx = x >= 0 ? asz[x] : 0;
+    bool alive = x >= 0 && sx > 0;
+    const int64_t rx = alive ? rowoff[x] : 0;
+    const int cx = alive ? mcol[x] : 0;
+    bool survives = alive;
+    float la[WB_K], lbv[WB_K];
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) { // all reads of the thread in flight together
+        la[j] = 0.0f;
+        lbv[j] = 0.0f;
+        if (j < nb && alive) {
+            la[j] = Dtri[pa[j] > x ? roa[j] + cx : rx + mca[j]];
+            lbv[j] = Dtri[pb[j] > x ? rob[j] + cx : rx + mcb[j]];
+            survives = survives && x != pa[j] && x != pb[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WB_K; ++j) {
+        unsigned long long key = ~0ull, key2 = ~0ull;
+        if (j < nb) {
+            alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
+            if (alive && sx + psa[j] + psb[j] <= max_size) {
+                const float v = ward_lb_value(fabsf(la[j]), fabsf(lbv[j]), pv[j], psa[j], psb[j], sx, g1, delta2);
+                Dtri[ron[j] + cx] = wflag(v);
+                key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
+                if (survives) key2 = key;
+            }
+        }
+        key = wave_umin64(key);
+        key2 = wave_umin64(key2);
+        if (lane == 0) {
+            wk[wave][j][0] = key;
+            wk[wave][j][1] = key2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * WB_K) { // one atomic per workgroup, row and key
+        const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
+        unsigned long long k = ~0ull;
+        for (int w = 0; w < WL_THREADS / 64; ++w) k = wk[w][j][which] < k ? wk[w][j][which] : k;
+        if (k != ~0ull) atomicMin(which ? &st->B.ckey2[j] : &st->B.ckey[j], k);
+    }
+    WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg3[3], wall_clock64());)
+}
+
 // finish for a batch: (1) validate + commit the longest valid prefix of the tentative picks (bookkeeping of
 // MergeClusters / RemoveClusters, clustering.go:29-58,:240-241; centroid images into CT4 / Crow; slot compaction);
 // (2) choose the next batch from {rows just created} U {preselected old-row pairs}; (3) merged centroids (:37-40).
@@ -3153,7 +3383,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             rowmin[a] = ICL_MAXF;
             rowmin[b] = ICL_MAXF;
             rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
-            rownn[c] = key == ~0ull ? -1 : (int)(key & 0xffffffffu);
+            rownn[c] = key == ~0ull ? -1 : rf.lb ? WB_NN_BOUND : (int)(key & 0xffffffffu); // (lb mode: the key's value is a lower bound of the row's minimum)
         }
         if (full0 && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
             rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
@@ -3404,7 +3634,7 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
                     bool died = false;
                     for (int i = j + 1; i < J; ++i) died |= (x == ls.B.a[i]) | (x == ls.B.b[i]); // its minimum partner was merged later in the same batch
                     crow[j] = (int)(n + t0 + j);
-                    cnn[j] = died ? -2 : x;
+                    cnn[j] = (died || rf.lb) ? -2 : x; // (lb mode: a lower bound, never a pick: the batch ends where it would come first)
                     cval[j] = __uint_as_float((unsigned)(key >> 32));
                     cused[j] = false;
                 }
@@ -3559,7 +3789,10 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
             }
             block_argmin(bv, bi, sv, si);
             if (bi < 0) break;
-            if (threadIdx.x == 0) sh[1] = asz[rownn[bi]] > 0 ? 0 : 1;
+            if (threadIdx.x == 0) {
+                const int nn0 = rownn[bi];
+                sh[1] = (nn0 >= 0 && asz[nn0] > 0) ? 0 : 1; // (WB_NN_BOUND: never scanned)
+            }
             __syncthreads();
             const int dirty = sh[1];
             __syncthreads();
@@ -4052,6 +4285,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     // the row scans (distance_mfma.hip "Distance BOUNDS", scan_row_refine above); ctx->ward_dist == 1 (icl_set_ward_options) or shapes
     // the bound does not cover: every value by ward_dist_exact_kernel.  Rows deposited by other GPUs are values.
     wrefine rf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
+    bool lbm = false;
     struct free_guard {
         void *p = nullptr;
         ~free_guard() { if (p) (void)hipFree(p); }
@@ -4071,6 +4305,16 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
 #endif
         rf = wrefine{d_E, w->nrm, n, d, (float)((gD / 2 + 16 * u) * (1 + 64 * u) * (1 + 1e-6)), (float)(gp * (1 + 1e-6)), stat, 0.0f};
         ICL_TRY(icl_dist_center_launch(ctx, d_E, n, d, K, w->colsum, (float *)g_ec.p, w->nrm, ctx->stream));
+        // lb mode (ICL_DIST_LWBOUND): the rows of new clusters are Lance-Williams lower bounds too (ward_update_lb_kernel); needs the packed
+        // column words, whole k-groups, the batched loop on one GPU
+        lbm = ctx->ward_dist == ICL_DIST_LWBOUND && mpk && (d & 3) == 0 && !ctx->shard;
+        if (lbm) {
+            rf.Crow = w->Crow;
+            rf.id_slot = w->id_slot;
+            rf.asz = w->asz;
+            rf.lb = 1;
+            hipLaunchKernelGGL(ward_lb_consts_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->nrm, w->colsum, n, d, max_size, w->st);
+        }
         ICL_TRY(icl_dist_bound_launch(ctx, (const float *)g_ec.p, w->nrm, w->zero, n, K, rf.ceps, rf.gam, w->Dtri, w->rowoff, own_lo / DT_TILE,
                                       icl_ceil_div(own_hi, DT_TILE), ctx->stream));
     } else
@@ -4135,6 +4379,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
     constexpr int GRAPH_STEPS = 64;
     const bool batched = batch_env; // both modes: exact centroid chains, or Lance-Williams rows (lw)
+    if (lbm && !batched) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "ICL_DIST_LWBOUND needs the batched merge loop");
     ward_state hst;
     if (batched) {
         // Batched exact mode: each step attempts up to WB_K independent merges, so the number of steps is data
@@ -4165,7 +4410,13 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
                                    w->cn_stride, w->cnewI, w->st);
         };
+        const unsigned lb_blocks = (unsigned)icl_ceil_div(w->S, WL_THREADS) + 2 + WB_R;
         auto update_b = [&]() {
+            if (lbm) {
+                hipLaunchKernelGGL(ward_update_lb_kernel, dim3(lb_blocks), dim3(WL_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff, w->mcol, w->msz,
+                                   w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn, rf, mpk);
+                return;
+            }
             if (lw) {
                 hipLaunchKernelGGL(ward_update_batch_lw_kernel, dim3(lw_blocks_b), dim3(WB_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff,
                                    w->mcol, w->msz, w->mcid, w->Dtri, w->st, max_size, n, w->rowmin, w->rownn);
@@ -4208,7 +4459,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             return true;
         };
         const bool use_graph = !sh && !prof_update && T >= 2 * GRAPH_STEPS;
-        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
+        if (use_graph && (!w->graph_exec || w->graph_max_size != max_size || w->graph_lw != (lw ? 3 : lbm ? 4 : 2) || w->graph_E != rf.E || w->graph_ceps != rf.ceps)) {
             if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
             w->graph_exec = nullptr;
             hipGraph_t graph = nullptr;
@@ -4219,7 +4470,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
             (void)hipGraphDestroy(graph);
             if (ge != hipSuccess) return icl_fail(ctx, ICL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
             w->graph_max_size = max_size;
-            w->graph_lw = lw ? 3 : 2;
+            w->graph_lw = lw ? 3 : lbm ? 4 : 2;
             w->graph_E = rf.E;
             w->graph_ceps = rf.ceps;
         }
@@ -4329,8 +4580,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ctx->ward_stats[2] = hst.B.slow;
         ctx->ward_stats[3] = (int64_t)hst.B.sum_live;
         if (prof_update) { // algorithmic work of the launches just profiled (n_live is only known on the device)
-            ctx->prof[ICL_K_UPDATE].flops += (lw ? 8.0 : 3.0 * d) * (double)hst.B.sum_live_nb;
-            ctx->prof[ICL_K_UPDATE].bytes += lw ? 12.0 * (double)hst.B.sum_live_nb : 4.0 * d * (double)hst.B.sum_live + 4.0 * (double)hst.B.sum_live_nb;
+            ctx->prof[ICL_K_UPDATE].flops += (lw ? 8.0 : lbm ? 16.0 : 3.0 * d) * (double)hst.B.sum_live_nb;
+            ctx->prof[ICL_K_UPDATE].bytes += (lw || lbm) ? 12.0 * (double)hst.B.sum_live_nb : 4.0 * d * (double)hst.B.sum_live + 4.0 * (double)hst.B.sum_live_nb;
         }
     } else {
         ctx->ward_stats[1] = nmerge;
@@ -4477,7 +4728,7 @@ extern "C" int icl_cluster_prefilled_dev(icl_ctx *ctx, const float *d_E, int64_t
 
 extern "C" int icl_set_ward_options(icl_ctx *ctx, int dist_mode)
 {
-    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_BOUND_INIT) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
+    if (!ctx || dist_mode < ICL_DIST_AUTO || dist_mode > ICL_DIST_LWBOUND) return icl_fail(ctx, ICL_ERR_ARG, "icl_set_ward_options: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->ward_dist = dist_mode;
     return ICL_OK;

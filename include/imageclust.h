@@ -219,7 +219,11 @@ int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int
  * always values from the exact vector-ALU kernel (round 3 also offered them as bounds: parity-green, slower, retired; the
  * old name ICL_DIST_BOUND_INIT stays as an alias of ICL_DIST_BOUND).  ICL_DIST_AUTO (default): ICL_DIST_BOUND for n >= 4096,
  * ICL_DIST_EXACT below. */
-enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3 };
+enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3,
+       /* ICL_DIST_BOUND plus: the rows UpdateDistanceMatrix (clustering.go:76-96) gives the new clusters are proven lower bounds as well,
+        * from the Lance-Williams recurrence on the stored entries (12 bytes instead of 3 D operations per entry), evaluated exactly on
+        * demand like the bounds of the initial matrix.  Same results bit for bit. */
+       ICL_DIST_LWBOUND = 4 };
 int icl_set_ward_options(icl_ctx *ctx, int dist_mode);
 /* The merge sequence of the last icl_cluster call on this context: pairs (creation id of the higher-position
  * cluster, creation id of the lower-position one); returns the number of merges performed. */

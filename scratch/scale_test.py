@@ -13,12 +13,14 @@ if __name__ == "__main__":
     ap.add_argument("--lw", action="store_true")
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--d", type=int, default=2048)
+    ap.add_argument("--dist-mode", type=int, default=0, help="icl_set_ward_options: 0 auto, 1 exact, 2 bounds in the initial matrix, 4 + Lance-Williams bound rows")
     ap.add_argument("--real", action="store_true", help="cluster the bf16 ResNet50 embeddings of the bench's structured synthetic images instead of the mixture of Gaussians")
     a = ap.parse_args()
     if a.lib:
         _lib.SO_PATH = a.lib
     n, d = a.n, a.d
     ctx = _lib.Context(0)
+    ctx.set_ward_options(a.dist_mode)
     if a.real:
         ctx.load_synthetic(1)
         imgs = torch.empty(n * _lib.IMG_BYTES, dtype=torch.uint8, device="cuda")
