@@ -359,7 +359,7 @@ class Context:
         return cid[:n], rank[:n], nc.value
 
     def set_ward_options(self, dist_mode=0):
-        """0 auto, 1 exact distances everywhere, 2 distance bounds + on-demand exact evaluation, 3 bounds in the initial matrix only (include/imageclust.h ICL_DIST_*)."""
+        """0 auto, 1 exact distances everywhere, 2 (= 3) distance bounds in the initial matrix + on-demand exact evaluation, 4 the rows of new clusters as Lance-Williams lower bounds too (include/imageclust.h ICL_DIST_*)."""
         check(self.h, self.L.icl_set_ward_options(self.h, dist_mode))
 
     def embed_cluster_dev(self, d_imgs, n, d_E, min_size, max_size, prec=PREC_BF16, update=UPDATE_EXACT, overlap=True):

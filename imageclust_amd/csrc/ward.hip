@@ -4225,6 +4225,16 @@ static int assign_ids(icl_ctx *ctx, int64_t n, int32_t min_size, int32_t max_siz
 // own_lo / own_hi: rows of the initial distance matrix this call computes itself (whole 128-row tile rows; everything by
 // default).  The other rows must already sit in the matrix (icl_ward_unpack_spans_dev): the multi-GPU paths compute them on
 // the other GPUs, and this GPU reads them over xGMI.
+// ICL_WARD_BATCH=0 (read once per process): the one-merge-per-step pipeline, kept as the witness of the parity tests
+static bool ward_batch_env()
+{
+    static const bool on = [] {
+        const char *e = getenv("ICL_WARD_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, int32_t min_size, int32_t max_size, int update,
                           int32_t *cluster_id, int32_t *member_rank, int32_t *n_clusters, int64_t own_lo = 0, int64_t own_hi = -1)
 {
@@ -4307,7 +4317,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         ICL_TRY(icl_dist_center_launch(ctx, d_E, n, d, K, w->colsum, (float *)g_ec.p, w->nrm, ctx->stream));
         // lb mode (ICL_DIST_LWBOUND): the rows of new clusters are Lance-Williams lower bounds too (ward_update_lb_kernel); needs the packed
         // column words, whole k-groups, the batched loop on one GPU
-        lbm = ctx->ward_dist == ICL_DIST_LWBOUND && mpk && (d & 3) == 0 && !ctx->shard;
+        // (auto: wherever the bounds of the initial matrix are; ICL_DIST_BOUND keeps exact rows)
+        lbm = (ctx->ward_dist == ICL_DIST_LWBOUND || ctx->ward_dist == ICL_DIST_AUTO) && mpk && (d & 3) == 0 && !ctx->shard && ward_batch_env();
         if (lbm) {
             rf.Crow = w->Crow;
             rf.id_slot = w->id_slot;
@@ -4341,10 +4352,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const unsigned upd_blocks = (unsigned)(w->S / 64) + 2; // 64 slots per workgroup + preselect + compaction workgroups
     const int dqp = (int)upd_groups(d);
     const size_t upd_lds = (size_t)(dqp + UPD_PAD_G) * 16 + (size_t)2 * UPD_SG * 64 * 16; // new centroid image + p ring
-    static const bool batch_env = [] {
-        const char *e = getenv("ICL_WARD_BATCH");
-        return !(e && e[0] == '0');
-    }();
+    const bool batch_env = ward_batch_env();
     if (!batch_env && upd_lds > 64 * 1024 && w->upd_attr_bytes < upd_lds) { // one-merge-per-step pipeline only; per context, i.e. per device
         hipFuncAttributes fa;
         ICL_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)ward_update_exact_kernel));
@@ -4379,7 +4387,6 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
     const bool prof_update = (ctx->prof_mask >> ICL_K_UPDATE) & 1;
     constexpr int GRAPH_STEPS = 64;
     const bool batched = batch_env; // both modes: exact centroid chains, or Lance-Williams rows (lw)
-    if (lbm && !batched) return icl_fail(ctx, ICL_ERR_UNSUPPORTED, "ICL_DIST_LWBOUND needs the batched merge loop");
     ward_state hst;
     if (batched) {
         // Batched exact mode: each step attempts up to WB_K independent merges, so the number of steps is data

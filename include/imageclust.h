@@ -217,8 +217,8 @@ int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_hwc_rgb, int64_t n, int
  * made exact on demand -- the reference's own sequential fp32 expression -- by the row scans of the merge loop; the same
  * cluster ids, member order, merge log and merge values, bit for bit.  UpdateDistanceMatrix's new rows (clustering.go:75-108) are
  * always values from the exact vector-ALU kernel (round 3 also offered them as bounds: parity-green, slower, retired; the
- * old name ICL_DIST_BOUND_INIT stays as an alias of ICL_DIST_BOUND).  ICL_DIST_AUTO (default): ICL_DIST_BOUND for n >= 4096,
- * ICL_DIST_EXACT below. */
+ * old name ICL_DIST_BOUND_INIT stays as an alias of ICL_DIST_BOUND).  ICL_DIST_AUTO (default): ICL_DIST_LWBOUND for n >= 4096 (with
+ * exact rows like ICL_DIST_BOUND where its conditions do not hold: D % 4 != 0, a sharded group call), ICL_DIST_EXACT below. */
 enum { ICL_DIST_AUTO = 0, ICL_DIST_EXACT = 1, ICL_DIST_BOUND = 2, ICL_DIST_BOUND_INIT = 3,
        /* ICL_DIST_BOUND plus: the rows UpdateDistanceMatrix (clustering.go:76-96) gives the new clusters are proven lower bounds as well,
         * from the Lance-Williams recurrence on the stored entries (12 bytes instead of 3 D operations per entry), evaluated exactly on

@@ -289,6 +289,53 @@ def test_distance_bounds_mode_on_every_small_case(ctx):
         ctx.set_ward_options(0)
 
 
+def test_lance_williams_bound_rows_on_every_small_case_and_the_adversarial_batches(ctx):
+    """ICL_DIST_LWBOUND forced (auto mode only uses it from n = 4096): the rows UpdateDistanceMatrix gives the new clusters are proven
+    lower bounds from the Lance-Williams recurrence, every row may hold flagged entries, picks come from exactly re-minimised rows only
+    and batches are validated against the new rows' lower bounds.  Ties, duplicates (bounds of 0: everything is evaluated), NaN / Inf,
+    rolled-back batches, new clusters that are each other's nearest neighbours, targets reached inside a batch, D = 4096; ids, member
+    order, merge log and every merge value against both oracles.  (D % 4 != 0 keeps exact rows: those cases run as ICL_DIST_BOUND.)"""
+    ctx.set_ward_options(4)
+    try:
+        for name, E, mn, mx in WC.small_cases():
+            try:
+                same_as_oracle(ctx, E, mn, mx)
+                same_as_fast_oracle(ctx, E, mn, mx)
+            except AssertionError as e:
+                raise AssertionError("%s: %s" % (name, e))
+        test_batch_dependent_chain(ctx)
+        test_batch_new_clusters_merge_with_each_other(ctx)
+        for args in [(100, 4096, 2, 10), (90, 2052, 1, 7), (700, 6, 1, 9), (600, 8, 2, 40)]:
+            test_batch_paths_wide_and_odd_dims(ctx, *args)
+        test_batch_heavy_ties_at_scale(ctx)
+        test_batch_target_reached_inside_a_batch(ctx)
+        same_as_oracle(ctx, np.ones((37, 8), np.float32), 2, 4)
+        E = mog(40, 8, 3)
+        E[7, 2] = np.nan
+        E[11, 0] = np.inf
+        same_as_oracle(ctx, E, 1, 3)
+        same_as_fast_oracle(ctx, WC.mog(3000, 2048, 4), 3, 6)
+        same_as_fast_oracle(ctx, WC.ties(1100, 4, 2, levels=5), 2, 9)
+        grid = np.random.default_rng(3).integers(0, 3, (600, 8)).astype(np.float32)  # thousands of exact ties and duplicates (bounds of 0)
+        for mn, mx in [(1, 600), (2, 12)]:
+            same_as_oracle(ctx, grid, mn, mx)
+        same_as_fast_oracle(ctx, WC.quadruples(seed=5, groups=250), 1, 1000)
+    finally:
+        ctx.set_ward_options(0)
+
+
+def test_exact_rows_and_bound_rows_agree_with_the_oracle_at_n24000(ctx):
+    """The two ways the exact mode fills a new cluster's row -- 3 D unfused operations per entry (ICL_DIST_BOUND) and Lance-Williams
+    lower bounds evaluated on demand (ICL_DIST_LWBOUND, what auto picks here) -- on one multi-block input against ward_fast.c."""
+    E = WC.mog(24000, 16, 1)
+    for mode in (2, 4):
+        ctx.set_ward_options(mode)
+        try:
+            same_as_fast_oracle(ctx, E, 5, 50)
+        finally:
+            ctx.set_ward_options(0)
+
+
 def test_distance_bounds_equal_exact_distances_on_near_ties(ctx):
     """Bounds vs exact initial distances on inputs built to crowd the band: N = 6000 points that are tiny perturbations of 300
     centres (pairs inside a group differ in the last bits), D = 96, and an integer grid with thousands of exact ties.  The two
@@ -396,7 +443,12 @@ def test_config2_full_size_two_pipelines_agree_100k(ctx):
     from tests import ward_pipeline_child as C
 
     args = (100000, 2048, 20250218, 5, 50)
-    mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])
+    mine = C.digests(ctx, C.make_E(*args[:3]), args[3], args[4])  # (auto: bounds in the initial matrix and in the new clusters' rows)
+    ctx.set_ward_options(2)  # the batched pipeline with exact rows for the new clusters
+    try:
+        assert C.digests(ctx, C.make_E(*args[:3]), args[3], args[4]) == mine
+    finally:
+        ctx.set_ward_options(0)
     env = dict(os.environ, ICL_WARD_BATCH="0", ICL_CHILD_DIST="1")  # the witness also builds every initial distance with the exact kernel
     p = subprocess.run([sys.executable, os.path.join(here, "ward_pipeline_child.py"), *map(str, args)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
