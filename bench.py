@@ -160,7 +160,7 @@ def main():
                          "rank 0 fills the whole matrix itself with the matrix-core bounds (0.19 s at 100 000 images, nothing to transport); "
                          "auto = local: 0.49 s / N of exact arithmetic + the transport only beat 0.19 s from about 6 ranks on (estimated "
                          "0.12 s at 8), and the local build needs no point-to-point traffic at all")
-    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound"], default="auto",
+    ap.add_argument("--ward-dist", choices=["auto", "exact", "bound", "lwbound"], default="auto",
                     help="exact mode only (include/imageclust.h ICL_DIST_*): how distances are produced -- every value on the vector ALUs, "
                          "or proven lower bounds from the matrix cores in the initial matrix with exact evaluation on demand (same ids, bit for "
                          "bit; UpdateDistanceMatrix's new rows are always exact values); auto: bounds for n >= 4096")
@@ -196,7 +196,7 @@ def main():
     from imageclust_amd import distributed as D
 
     ctx = _lib.Context(local_rank)
-    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2}[args.ward_dist])
+    ctx.set_ward_options({"auto": 0, "exact": 1, "bound": 2, "lwbound": 4}[args.ward_dist])
     ctx.load_synthetic(1)
     ctx.set_batch(args.batch)
     if args.scaling == "weak":
@@ -353,12 +353,14 @@ def main():
         if upd and upd["launches"]:
             ws = ctx.last_ward_stats()
             gbs = upd["bytes"] / max(upd["ms"], 1e-9) / 1e6  # GB/s
-            exact = args.update == "exact"
+            # rows of new clusters: Lance-Williams lower bounds evaluated on demand (auto from n = 4096, D % 4 == 0) or 3 D exact operations per entry
+            lb_rows = args.update == "exact" and (args.ward_dist == "lwbound" or (args.ward_dist == "auto" and n_total >= 4096)) and DIM % 4 == 0 and world >= 1
+            exact = args.update == "exact" and not lb_rows
             tfl = upd["flops"] / max(upd["ms"], 1e-9) / 1e9  # 3 flop per (pair, k): sub, mul, add -- unfused by construction
             # What binds the exact update is the vector ALU (16 rows x 3 unfused fp32 ops per byte-quad: 12 flop/B), not HBM:
             # `bound` says so, achieved / peak / frac are the vector-fp32 figures, the HBM view sits beside them in `hbm`.
             # (The Lance-Williams update of --update lw reads 12 bytes per pair: that one IS an HBM kernel.)
-            ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_batch_lw_kernel",
+            ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_lb_kernel" if lb_rows else "ward_update_batch_lw_kernel",
                          "achieved": round(tfl, 2) if exact else round(gbs, 1), "peak": PEAK_F32_TFLOPS if exact else PEAK_HBM_GBS,
                          "unit": "TFLOP/s" if exact else "GB/s",
                          "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
@@ -385,6 +387,15 @@ def main():
                          "total_ms_in_profile_pass": round(upd["ms"], 1),
                          "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
                                      "(the timed steps replay a hipGraph)"}
+            if lb_rows:  # the exact-update fields do not describe this kernel
+                for k in ("valu", "traffic_note"):
+                    ward_roof.pop(k, None)
+                ward_roof["algorithmic_unit"] = ("12 bytes per (new row, live cluster): two stored entries read, one lower bound written -- the Lance-Williams "
+                                                 "recurrence on the distance matrix instead of 3*D operations on the centroids (SURVEY.md 8d's 4*n*D per merge no longer "
+                                                 "moves); the bytes of the row re-scans that ride in the same launch (8 bytes x N columns each) are not counted")
+                ward_roof["note"] = ("the launch is bound by LATENCY, not by HBM or the vector ALUs: its length is the chain phase A (row-cache slices) -> flag barrier "
+                                     "-> one or two row re-scans + one exact evaluation (a chain of D dependent fp32 additions) per spare workgroup -> preselection; "
+                                     "`frac` of the HBM peak is therefore small by construction (DESIGN.md section 3, per-step timeline)")
         conv_roof["total_ms_in_profile_pass"] = round(c128["ms"], 1)
         # `roofline` = the dominant kernel of THIS workload by GPU time in the profiling passes (at N=100 000 the batched Ward
         # update, vector-ALU bound; at configs[1]'s N=10 000 the Cout >= 128 convolutions, MFMA bound); the other one sits beside it
@@ -410,7 +421,7 @@ def main():
                                                                      else " -> RCCL all-gather of E -> rank 0 builds the whole distance matrix itself (matrix-core bounds)") if world > 1 else "")))
                                    + ("" if args.embed_only else " -> Ward min=%d max=%d (merge loop on GPU0) -> cluster ids on host" % (args.min_size, args.max_size)),
                        "n_images_total": n_total, "embed_dim": DIM, "weights": "synthetic seed 1", "device": name,
-                       "ward_update": "none (embed only)" if args.embed_only else "exact (ids bit-identical to the reference)" if args.update == "exact"
+                       "ward_update": "none (embed only)" if args.embed_only else "exact (ids bit-identical to the reference; new clusters' rows: Lance-Williams lower bounds, evaluated exactly on demand)" if (args.update == "exact" and (args.ward_dist == "lwbound" or (args.ward_dist == "auto" and n_total >= 4096))) else "exact (ids bit-identical to the reference)" if args.update == "exact"
                        else "lw (MFMA distance tile + Lance-Williams, not bit-identical)"},
             "stages_ms_last_step": {k: round(v, 3) for k, v in result.items() if k.endswith("_ms")},
             "stages_note": ("N=1: embed_ms includes the distance rows that ran beside the forward passes on a side stream; dist_ms is what was left "

@@ -60,7 +60,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #endif
 #define WB_K 16 /* merges attempted per batched step (a power of two: lane-indexed tables): N=100k takes 15.6 merges per step */
 #ifndef WB_R
-#define WB_R 48 /* workgroups that re-minimise rows whose cached partner is a member of the batch (<= 64: one lane each in their flag barrier) */
+#define WB_R 64 /* workgroups that re-minimise rows whose cached partner is a member of the batch (<= 64: one lane each in their flag barrier).  48 until the
+                   rows of new clusters became Lance-Williams bounds (the main workgroups no longer need the CUs): merge loop 985 -> 910 ms at N=100k */
 #endif
 #ifndef WB_SCAN_U
 #define WB_SCAN_U 4 /* 16-byte loads of each of a row scan's three streams (values, sizes, ids) a lane keeps in flight */
