@@ -76,9 +76,19 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int wb_poll(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wb_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 #define WB_NN_BOUND (-2) /* rownn of a row whose cache is only a LOWER bound of its minimum (lb mode: a row of Lance-Williams bounds that was never scanned) */
+#ifndef WB_LAZY_TOP
+#define WB_LAZY_TOP 1 /* 1: the spare workgroups re-minimise only the stale rows among each slice's WB_WTOP smallest keys -- the rows the preselection can reach
+                         in this step -- (a row whose partner is in the batch / has died / that was never scanned, WB_NN_BOUND); every other stale row stays
+                         lazy: its cached value remains a lower bound.  0 (until round 4): every row whose cached partner is a member of the batch, wherever it stands */
+#endif
 #define WB_PA_CAP 32 /* matched rows a slice can publish (WB_R * WB_RM = 96 are re-minimised per step; the rest stays lazy) */
 #define WB_WTOP 5    /* keys a wave / a slice reports before its sentinel */
 #define WB_PA_KEYS (WB_WTOP + 1)
+#ifndef WB_LOOK
+#define WB_LOOK 16   /* WB_LAZY_TOP: a slice's spare workgroup looks at its WB_LOOK smallest keys for stale rows (it publishes the first WB_WTOP): rows are made
+                        exact a few steps before the preselection can reach them, so the published lists hold clean rows */
+#endif
+#define WB_WPOP 8    /* keys a wave contributes to its slice's merge (WB_LAZY_TOP; otherwise WB_WTOP) */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
     int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
@@ -1851,22 +1861,18 @@ static inline int64_t wb_groups(int d) { return (((int64_t)d + 3) / 4 + WB_SG - 
 // shuffles and appends a SENTINEL (a lower bound for everything it did not report); wave 0 then walks the <= 50
 // entries in ascending order and stops at the first sentinel, so whatever it saw before is exact.
 #define WB_MAXOV 8
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(k, off, 64);
-        k = o < k ? o : k;
-    }
-    return k;
-}
+__device__ __forceinline__ unsigned long long wave_umin64(unsigned long long k);
+// (every lane active; wave-uniform result.  Until round 4 a 6-step __shfl_xor tree: twelve dependent ds_bpermute round trips per pop --
+// the 8 + 12 pops of a slice and the preselection's walk sit on the update launch's critical chain)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k) { return wave_umin64(k); }
 
 // Pops the WB_WTOP smallest keys of a wave (every lane offers k1 < k2, its two smallest; a key with bit 0 set is a SENTINEL:
 // a lower bound of entries that are not listed) into out[0..WB_WTOP), then out[WB_WTOP] = a sentinel for whatever the wave
 // did not report.  A reader that walks such streams in ascending order and stops at the first sentinel has seen every key
 // below it.  Keys are unique (one per row).
 // has_rest: the lane has seen more entries than the two it offers (its own sentinel k2|1 follows k2); ntop keys are popped.
-__device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned long long k2, bool has_rest, unsigned long long *out, int ntop, int lane)
+__device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned long long k2, bool has_rest, unsigned long long *out, int ntop, int lane,
+                                             unsigned long long *kept = nullptr) // kept (optional): lane q < ntop receives out[q]
 {
     unsigned long long head = k1;
     int stg = 0; // 0: head = k1, 1: head = k2, 2: head = sentinel(k2)
@@ -1874,6 +1880,7 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
     for (int q = 0; q < ntop; ++q) {
         const unsigned long long m = ended ? ~0ull : wave_min_u64(head);
         if (lane == 0) out[q] = m;
+        if (kept && lane == q) *kept = m;
         if (m == ~0ull || (m & 1ull)) { // nothing left / a lane ran out of known entries: the wave's list ends here
             ended = true;
             continue;
@@ -1904,7 +1911,10 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     __shared__ int lcnt;
     __shared__ int lrows[WB_PA_CAP];
     __shared__ int mine[WB_RM];
-    __shared__ unsigned long long wstream[16 * WB_PA_KEYS];
+    constexpr int WPOP = WB_LAZY_TOP ? WB_WPOP : WB_WTOP; // keys per wave, then its sentinel
+    __shared__ unsigned long long wstream[14 * (WPOP + 1)];
+    __shared__ unsigned long long mk[WB_LOOK + 1];
+    static_assert(14 * (WPOP + 1) <= 128 && WB_LOOK >= WB_WTOP + 1 && WB_LOOK < 64, "the slice's merge holds two entries per lane");
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
     if (nb <= 0 || t0 + nb >= st->target) return;
@@ -1941,7 +1951,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
             }
             dep |= nnv[e] == WB_NN_BOUND; // (lb mode) a row that has never been scanned: made exact one step after its creation
             if (self) continue; // the batch's own members are dead if it commits
-            if (dep) {
+            if (!WB_LAZY_TOP && dep) {
                 const int at = atomicAdd(&lcnt, 1);
                 if (at < WB_PA_CAP) lrows[at] = r; // beyond the cap: left to the lazy path (exact, just later)
             }
@@ -1954,11 +1964,12 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
                 k2 = k;
         }
     }
-    wave_pop_top(k1, k2, nseen > 2, &wstream[wave * WB_PA_KEYS], WB_WTOP, lane);
+    if (nwave > 14) __builtin_trap(); // (the workgroups of this file have <= 12 waves; a wave left out would break the streams' coverage claim)
+    wave_pop_top(k1, k2, nseen > 2, &wstream[wave * (WPOP + 1)], WPOP, lane);
     __syncthreads();
     if (wave == 0) {
-        // merge the nwave streams (<= 16 * 6 = 96 entries): each lane offers up to two entries, smaller first
-        const int tot = nwave * WB_PA_KEYS;
+        // merge the nwave streams (<= 14 * 9 = 126 entries): each lane offers up to two entries, smaller first
+        const int tot = nwave * (WPOP + 1);
         unsigned long long e1 = lane < tot ? wstream[lane] : ~0ull, e2 = lane + 64 < tot ? wstream[lane + 64] : ~0ull;
         if (e2 < e1) {
             const unsigned long long tmp = e1;
@@ -1966,7 +1977,35 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
             e2 = tmp;
         }
         // (an entry that is itself a sentinel ends the merged stream when it reaches the head: wave_pop_top tests bit 0)
-        wave_pop_top(e1, e2, false, st->B.pa_keys[wg], WB_WTOP, lane);
+        unsigned long long kept = ~0ull; // lane q: the slice's q-th smallest key
+        if (!WB_LAZY_TOP)
+            wave_pop_top(e1, e2, false, st->B.pa_keys[wg], WB_WTOP, lane, &kept);
+        else {
+            // the slice's WB_LOOK smallest keys: the first WB_WTOP are published, the next one (as a sentinel) bounds everything else
+            wave_pop_top(e1, e2, false, mk, WB_LOOK, lane, &kept);
+            if (lane < WB_WTOP) st->B.pa_keys[wg][lane] = kept;
+            if (lane == WB_WTOP) st->B.pa_keys[wg][WB_WTOP] = kept == ~0ull ? kept : (kept | 1ull);
+            // the stale rows among them are this slice's matched rows
+            bool stale = false;
+            int r = -1;
+            if (lane < WB_LOOK && kept != ~0ull && !(kept & 1ull)) {
+                r = (int)((kept & 0xffffffffull) >> 1);
+                const int nn = rownn[r];
+                if (nn == WB_NN_BOUND)
+                    stale = true;
+                else if (nn >= 0) {
+                    stale = asz[nn] <= 0;
+#pragma unroll
+                    for (int z = 0; z < 2 * WB_K; ++z) stale |= nn == ex[z];
+                }
+            }
+            const unsigned long long sm = __ballot(stale);
+            if (stale) lrows[__popcll(sm & ((1ull << lane) - 1ull))] = r;
+            if (lane == 0) lcnt = __popcll(sm);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         const int c = lcnt < WB_PA_CAP ? lcnt : WB_PA_CAP;
         if (lane < c) st->B.pa_rows[wg][lane] = lrows[lane];
         if (lane == 0) st->B.pa_cnt[wg] = c;
@@ -2129,13 +2168,15 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                     if (lane == src) key = ~0ull;
                     continue;
                 }
-                if (!ralive && rn != WB_NN_BOUND) { // its cached partner has really died: exact rescan, written back
+                if (!WB_LAZY_TOP && !ralive && rn != WB_NN_BOUND) { // its cached partner has really died: exact rescan, written back
                     action = 2;
                     arow = r;
                     alane = src;
                     break;
                 }
-                bool in_batch = rn == WB_NN_BOUND, in_picks = false; // (a bound row: the spare workgroups have re-minimised it without the batch's members, like a row whose partner is in the batch)
+                // a stale row (partner dead, or never scanned: WB_NN_BOUND): the spare workgroups have re-minimised it without the batch's members, like a
+                // row whose partner is in the batch
+                bool in_batch = rn == WB_NN_BOUND || (WB_LAZY_TOP && !ralive), in_picks = false;
 #pragma unroll
                 for (int z = 0; z < 2 * WB_K; ++z) {
                     in_batch |= ex[z] == rn;
@@ -2186,6 +2227,12 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                             }
                         }
                         continue; // the finish kernel installs this result itself
+                    }
+                    if (WB_LAZY_TOP && !ralive && rn != WB_NN_BOUND) { // (beyond the spare workgroups' capacity) the partner has really died: exact rescan, written back
+                        action = 2;
+                        arow = r;
+                        alane = src;
+                        break;
                     }
                     if (nov >= WB_MAXOV) break;
                     action = 3;
