@@ -1928,6 +1928,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
 #pragma unroll
     for (int z = 0; z < 2 * WB_K; ++z) ex[z] = __builtin_amdgcn_readfirstlane(excl[z]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    WB_TIMER(const unsigned long long ta0 = wall_clock64();)
     // ---- phase A: one pass over this workgroup's slice (int4 groups of rownn / float4 groups of rowmin)
     const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32 / -1
     const int64_t per = (nvec + WB_R - 1) / WB_R;
@@ -1965,8 +1966,10 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         }
     }
     if (nwave > 14) __builtin_trap(); // (the workgroups of this file have <= 12 waves; a wave left out would break the streams' coverage claim)
+    WB_TIMER(const unsigned long long ta1 = wall_clock64();)
     wave_pop_top(k1, k2, nseen > 2, &wstream[wave * (WPOP + 1)], WPOP, lane);
     __syncthreads();
+    WB_TIMER(const unsigned long long ta2 = wall_clock64();)
     if (wave == 0) {
         // merge the nwave streams (<= 14 * 9 = 126 entries): each lane offers up to two entries, smaller first
         const int tot = nwave * (WPOP + 1);
@@ -2009,8 +2012,15 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         const int c = lcnt < WB_PA_CAP ? lcnt : WB_PA_CAP;
         if (lane < c) st->B.pa_rows[wg][lane] = lrows[lane];
         if (lane == 0) st->B.pa_cnt[wg] = c;
+        WB_TIMER(const unsigned long long ta3 = wall_clock64();)
         __threadfence();
         if (lane == 0) __hip_atomic_store(&st->B.pa_flag[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        WB_TIMER(if (lane == 0 && wg == 0) {
+            g_scan_dbg[4] += ta1 - ta0; /* slice loop */
+            g_scan_dbg[5] += ta2 - ta1; /* wave pops + barrier */
+            g_scan_dbg[6] += ta3 - ta2; /* merge, stale look-ups */
+            g_scan_dbg[7] += wall_clock64() - ta3; /* fence + flag */
+        })
         // ---- barrier over the WB_R spare workgroups (all resident: they are the first workgroups of the grid)
         int ok = lane >= WB_R;
         for (int spin = 0; spin < 200000 && !__all(ok); ++spin) {
@@ -3086,6 +3096,7 @@ __global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__res
 }
 
 #define WL_THREADS 768
+#define WL_SLOTS 256 /* live clusters per main workgroup of ward_update_lb_kernel */
 // update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
 // the pairs of clusters created by this batch, then one lane per live cluster.
 __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
@@ -3159,45 +3170,54 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
         }
         return;
     }
-    const int64_t slot0 = ((int64_t)blockIdx.x - (WB_R + 2)) * WL_THREADS;
+    // a workgroup takes WL_SLOTS live clusters; its WL_THREADS / WL_SLOTS thread groups share the picks (group g: picks g, g + 3, ...): a third of
+    // the scattered reads per CU, three times the CUs (72 workgroups of 768 lanes at 55 000 live clusters held the launch for 74 us)
+    constexpr int NG = WL_THREADS / WL_SLOTS;
+    const int64_t slot0 = ((int64_t)blockIdx.x - (WB_R + 2)) * WL_SLOTS;
     if (slot0 >= nlive) return;
-    const int64_t slot = slot0 + threadIdx.x;
+    const int sub = (int)threadIdx.x / WL_SLOTS;
+    const int64_t slot = slot0 + (int)threadIdx.x % WL_SLOTS;
     const int x = slot < nlive && slot < S ? slot_id[slot] : -1;
     const int sx = x >= 0 ? asz[x] : 0;
-    bool alive = x >= 0 && sx > 0;
-    const int64_t rx = alive ? rowoff[x] : 0;
-    const int cx = alive ? mcol[x] : 0;
-    bool survives = alive;
-    float la[WB_K], lbv[WB_K];
+    const bool live = x >= 0 && sx > 0;
+    const int64_t rx = live ? rowoff[x] : 0;
+    const int cx = live ? mcol[x] : 0;
+    int jm = WB_K; // the pick x is a member of (WB_K: none): x is gone when c_jm is created, alive for the rows before it
 #pragma unroll
-    for (int j = 0; j < WB_K; ++j) { // all reads of the thread in flight together
-        la[j] = 0.0f;
-        lbv[j] = 0.0f;
-        if (j < nb && alive) {
-            la[j] = Dtri[pa[j] > x ? roa[j] + cx : rx + mca[j]];
-            lbv[j] = Dtri[pb[j] > x ? rob[j] + cx : rx + mcb[j]];
-            survives = survives && x != pa[j] && x != pb[j];
+    for (int j = WB_K - 1; j >= 0; --j)
+        if (j < nb && (x == pa[j] || x == pb[j])) jm = j;
+    const bool survives = live && jm == WB_K;
+    constexpr int NJ = (WB_K + NG - 1) / NG;
+    float la[NJ], lbv[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) { // all reads of the thread in flight together
+        const int j = sub + q * NG;
+        la[q] = 0.0f;
+        lbv[q] = 0.0f;
+        if (j < nb && live && j < jm) {
+            la[q] = Dtri[pa[j] > x ? roa[j] + cx : rx + mca[j]];
+            lbv[q] = Dtri[pb[j] > x ? rob[j] + cx : rx + mcb[j]];
         }
     }
+    for (int q = lane; q < WB_K * 2; q += 64) wk[wave][q >> 1][q & 1] = ~0ull; // (this wave's own entries; it fills the picks of its group below)
 #pragma unroll
-    for (int j = 0; j < WB_K; ++j) {
+    for (int q = 0; q < NJ; ++q) {
+        const int j = sub + q * NG;
         unsigned long long key = ~0ull, key2 = ~0ull;
-        if (j < nb) {
-            alive = alive && x != pa[j] && x != pb[j]; // members of p_0..p_j are gone when c_j is created
-            if (alive && sx + psa[j] + psb[j] <= max_size) {
-                const float v = ward_lb_value(fabsf(la[j]), fabsf(lbv[j]), pv[j], psa[j], psb[j], sx, g1, delta2);
-                Dtri[ron[j] + cx] = wflag(v);
-                key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
-                if (survives) key2 = key;
-            }
+        if (j < nb && live && j < jm && sx + psa[j] + psb[j] <= max_size) { // (members of p_0..p_j are gone when c_j is created)
+            const float v = ward_lb_value(fabsf(la[q]), fabsf(lbv[q]), pv[j], psa[j], psb[j], sx, g1, delta2);
+            Dtri[ron[j] + cx] = wflag(v);
+            key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)x;
+            if (survives) key2 = key;
         }
         key = wave_umin64(key);
         key2 = wave_umin64(key2);
-        if (lane == 0) {
+        if (lane == 0 && j < WB_K) {
             wk[wave][j][0] = key;
             wk[wave][j][1] = key2;
         }
     }
+    WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[2] += wall_clock64() - tm0;) // "virt" column of the print: main block 0 up to its rows' stores
     __syncthreads();
     if (threadIdx.x < 2 * WB_K) { // one atomic per workgroup, row and key
         const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
@@ -3206,6 +3226,7 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
         if (k != ~0ull) atomicMin(which ? &st->B.ckey2[j] : &st->B.ckey[j], k);
     }
     WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg3[3], wall_clock64());)
+    WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[1] += wall_clock64() - tm0;) // "main0": main block 0, whole
 }
 
 // finish for a batch: (1) validate + commit the longest valid prefix of the tentative picks (bookkeeping of
@@ -4465,7 +4486,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
                                    w->cn_stride, w->cnewI, w->st);
         };
-        const unsigned lb_blocks = (unsigned)icl_ceil_div(w->S, WL_THREADS) + 2 + WB_R;
+        const unsigned lb_blocks = (unsigned)icl_ceil_div(w->S, WL_SLOTS) + 2 + WB_R;
         auto update_b = [&]() {
             if (lbm) {
                 hipLaunchKernelGGL(ward_update_lb_kernel, dim3(lb_blocks), dim3(WL_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff, w->mcol, w->msz,
@@ -4619,6 +4640,8 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         (void)hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_scan_dbg), sizeof(gs));
         unsigned long long zero[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), zero, sizeof(zero));
+        fprintf(stderr, "[icl] spare workgroup 0, phase A per step us: slice loop %.1f, wave pops %.1f, merge + stale look-ups %.1f, fence + flag %.1f\n", gs[4] * 0.01 / hst.B.steps,
+                gs[5] * 0.01 / hst.B.steps, gs[6] * 0.01 / hst.B.steps, gs[7] * 0.01 / hst.B.steps);
         fprintf(stderr, "[icl] plain row scans: %llu, %.0f columns each, %.1f us in the load/visit loop, %.1f us in the reduce; per step us: first main start -> last main end %.1f, preselection start -> first main start %.1f, last main end -> finish start %.1f\n",
                 gs[2], (double)gs[3] / (gs[2] ? gs[2] : 1), gs[0] * 0.01 / (gs[2] ? gs[2] : 1), gs[1] * 0.01 / (gs[2] ? gs[2] : 1), hst.B.dbg4[0] * 0.01 / hst.B.steps,
                 hst.B.dbg4[2] * 0.01 / hst.B.steps, hst.B.dbg4[1] * 0.01 / hst.B.steps);
