@@ -2013,8 +2013,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         if (lane < c) st->B.pa_rows[wg][lane] = lrows[lane];
         if (lane == 0) st->B.pa_cnt[wg] = c;
         WB_TIMER(const unsigned long long ta3 = wall_clock64();)
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(&st->B.pa_flag[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&st->B.pa_flag[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // (the release orders this wave's stores above; a __threadfence() in front of it was a second L2 write-back, ~3 us)
         WB_TIMER(if (lane == 0 && wg == 0) {
             g_scan_dbg[4] += ta1 - ta0; /* slice loop */
             g_scan_dbg[5] += ta2 - ta1; /* wave pops + barrier */
@@ -2071,7 +2070,6 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         }
     }
     if (threadIdx.x == 0) {
-        __threadfence();
         __hip_atomic_store(&st->B.spec_done[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
