@@ -88,7 +88,10 @@ __device__ __forceinline__ void wb_acquire() { __builtin_amdgcn_fence(__ATOMIC_A
 #define WB_LOOK 16   /* WB_LAZY_TOP: a slice's spare workgroup looks at its WB_LOOK smallest keys for stale rows (it publishes the first WB_WTOP): rows are made
                         exact a few steps before the preselection can reach them, so the published lists hold clean rows */
 #endif
+#ifndef WB_WPOP
 #define WB_WPOP 8    /* keys a wave contributes to its slice's merge (WB_LAZY_TOP; otherwise WB_WTOP) */
+#endif
+#define WB_MAXWAVES (128 / (WB_WPOP + 1)) /* waves of a workgroup that runs ward_spec_rescan: its merge holds two entries per lane */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
     int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
@@ -1912,9 +1915,9 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     __shared__ int lrows[WB_PA_CAP];
     __shared__ int mine[WB_RM];
     constexpr int WPOP = WB_LAZY_TOP ? WB_WPOP : WB_WTOP; // keys per wave, then its sentinel
-    __shared__ unsigned long long wstream[14 * (WPOP + 1)];
+    __shared__ unsigned long long wstream[WB_MAXWAVES * (WB_WPOP + 1)];
     __shared__ unsigned long long mk[WB_LOOK + 1];
-    static_assert(14 * (WPOP + 1) <= 128 && WB_LOOK >= WB_WTOP + 1 && WB_LOOK < 64, "the slice's merge holds two entries per lane");
+    static_assert(WPOP <= WB_WPOP && WB_LOOK >= WB_WTOP + 1 && WB_LOOK < 64, "the slice's merge holds two entries per lane");
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
     if (nb <= 0 || t0 + nb >= st->target) return;
@@ -1965,7 +1968,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
                 k2 = k;
         }
     }
-    if (nwave > 14) __builtin_trap(); // (the workgroups of this file have <= 12 waves; a wave left out would break the streams' coverage claim)
+    if (nwave > WB_MAXWAVES) __builtin_trap(); // (the workgroups of this file have <= 12 waves; a wave left out would break the streams' coverage claim)
     WB_TIMER(const unsigned long long ta1 = wall_clock64();)
     wave_pop_top(k1, k2, nseen > 2, &wstream[wave * (WPOP + 1)], WPOP, lane);
     __syncthreads();
@@ -3093,7 +3096,9 @@ __global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__res
     }
 }
 
+#ifndef WL_THREADS
 #define WL_THREADS 768
+#endif
 #define WL_SLOTS 256 /* live clusters per main workgroup of ward_update_lb_kernel */
 // update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
 // the pairs of clusters created by this batch, then one lane per live cluster.
