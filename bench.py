@@ -37,7 +37,7 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 3857973248  # 53 conv + 1 fc, MACs x 2
 
 
-def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s=75.0, ctx=None):
+def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s=75.0, ctx=None, ward_mode=0):
     """The CPU restatement of the reference algorithm (oracle/, kind "port"), timed on this box's host cores as SURVEY.md
     8d prescribes: (i) embed = the fp32 ResNet50 restatement, batch 1, serial calls, all cores inside a call (OpenCV-DNN is
     internally multi-threaded, embeddings.go:133-141), 64 images; (ii) Ward = the literal O(N^3) restatement, ONE thread
@@ -83,7 +83,13 @@ def cpu_baseline(n_embed=64, ward_sizes=(64, 1000, 2000, 4000), d=2048, budget_s
         ref = O.cluster(E, mn, mx, want_log=True, threads=1)
         ward.append((n_ward, time.perf_counter() - t0))
         if ctx is not None:  # the same E through the engine: ids, member order and the merge sequence, bit for bit
-            cid, mr, nc = ctx.cluster(E, mn, mx)
+            # forced onto the kernels the timed 100 000-image step runs (auto would use exact rows below n = 4096): matrix-core bounds in the
+            # initial matrix and Lance-Williams lower bounds in the new clusters' rows, evaluated exactly on demand
+            ctx.set_ward_options(4)
+            try:
+                cid, mr, nc = ctx.cluster(E, mn, mx)
+            finally:
+                ctx.set_ward_options(ward_mode)
             same = bool(nc == ref["n_clusters"] and np.array_equal(cid, ref["cluster_id"]) and np.array_equal(mr, ref["member_rank"])
                         and np.array_equal(ctx.last_merges(), ref["log"][:, 2:4].astype(np.int32)))
             parity["ward_ids_and_log_equal_n%d" % n_ward] = same
@@ -431,13 +437,14 @@ def main():
             ("roofline_conv" if ward_dominates else "roofline_ward_update"): (conv_roof if ward_dominates else ward_roof),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], par = cpu_baseline(ctx=ctx)
+            out["cpu_baseline"], par = cpu_baseline(ctx=ctx, ward_mode={"auto": 0, "exact": 1, "bound": 2, "lwbound": 4}[args.ward_dist])
             # the throughput of the parity precision itself: one untimed 10 000-image pass of the fp32 (f32 MFMA) forward
             n10 = min(n_local, 10000)
             ctx.embed_u8_dev(imgs.data_ptr(), n10, E_local.data_ptr(), DIM, _lib.PREC_FP32)
             par["embed_fp32_img_per_s_10k"] = round(n10 / max(ctx.last_stage_ms()["embed_ms"], 1e-9) * 1e3, 1)
             par["note"] = ("checked in this run against oracle/ (CPU restatement of clustering.go / the ONNX graph): cluster ids, member order and the merge "
-                           "sequence of the exact Ward path on the cpu_baseline inputs; the fp32 embedding path on 4 images (tolerance 1e-4 of the "
+                           "sequence of the exact Ward path on the cpu_baseline inputs, forced onto the kernels of the timed step (ICL_DIST_LWBOUND: bounds in the "
+                           "initial matrix and in the new clusters' rows, exact evaluation on demand); the fp32 embedding path on 4 images (tolerance 1e-4 of the "
                            "output scale).  The timed steps above run the bf16 embedding (configs[1]) and the same exact Ward path.")
             out["parity"] = par
         print(json.dumps(out), flush=True)
