@@ -338,7 +338,7 @@ def main():
                     pmc = json.load(f)
                 convs = [v for k, v in pmc.items() if k.startswith("conv_igemm_kernel<BF16, 128") or k.startswith("conv3x3_halo_kernel<BF16, 128") or k.startswith("bneck56_kernel")]
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in convs) / max(sum(v["launches"] for v in convs), 1), 0)
-                upd_pmc = [v for k, v in pmc.items() if k.startswith("ward_update_batch2_kernel")]  # (a template since round 3: "...<false>" is the exact body)
+                upd_pmc = [v for k, v in pmc.items() if k.startswith("ward_update_lb_kernel") or k.startswith("ward_update_batch2_kernel")]  # (whichever the profiled run used)
                 traffic_upd = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in upd_pmc) / max(sum(v["launches"] for v in upd_pmc), 1), 0)
                 traffic_note = "(means over every launch of one bench.py run at N=100000; the ward figure includes the spare / preselection workgroups' row reads)"
                 pmc_file = cand
@@ -369,7 +369,7 @@ def main():
             ward_roof = {"bound": "valu" if exact else "hbm", "kernel": "ward_update_batch2_kernel" if exact else "ward_update_lb_kernel" if lb_rows else "ward_update_batch_lw_kernel",
                          "achieved": round(tfl, 2) if exact else round(gbs, 1), "peak": PEAK_F32_TFLOPS if exact else PEAK_HBM_GBS,
                          "unit": "TFLOP/s" if exact else "GB/s",
-                         "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if exact else None,
+                         "frac": round(tfl / PEAK_F32_TFLOPS, 4) if exact else round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_upd if (exact or lb_rows) else None,
                          "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                          "traffic_note": ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/%s %s" % (pmc_file, traffic_note)) if pmc_file else
                                          "PMC passes were taken at the default workload (100 000 images, bf16) only",
@@ -394,11 +394,11 @@ def main():
                          "measured": "HIP events around every launch in one extra untimed eager pass over the same E "
                                      "(the timed steps replay a hipGraph)"}
             if lb_rows:  # the exact-update fields do not describe this kernel
-                for k in ("valu", "traffic_note"):
-                    ward_roof.pop(k, None)
+                ward_roof.pop("valu", None)
                 ward_roof["algorithmic_unit"] = ("12 bytes per (new row, live cluster): two stored entries read, one lower bound written -- the Lance-Williams "
                                                  "recurrence on the distance matrix instead of 3*D operations on the centroids (SURVEY.md 8d's 4*n*D per merge no longer "
-                                                 "moves); the bytes of the row re-scans that ride in the same launch (8 bytes x N columns each) are not counted")
+                                                 "moves); the bytes of the row re-scans that ride in the same launch (8 bytes x N columns each, ~35 per launch) are not counted; `traffic` "
+                                                 "(PMC) is ~17x the algorithmic bytes: one of the two read directions walks a COLUMN of the 40 GB matrix, 4 useful bytes per 64-byte line")
                 ward_roof["note"] = ("the launch is bound by LATENCY, not by HBM or the vector ALUs: its length is the chain phase A (row-cache slices) -> flag barrier "
                                      "-> one or two row re-scans + one exact evaluation (a chain of D dependent fp32 additions) per spare workgroup -> preselection; "
                                      "`frac` of the HBM peak is therefore small by construction (DESIGN.md section 3, per-step timeline)")
