@@ -190,16 +190,20 @@ static bool inflate_exact(bits_in &b, std::vector<uint8_t> &out, size_t want)
 
 static uint32_t crc32_of(const uint8_t *p, size_t n)
 {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
+    // (a function-local static initialised by a lambda: thread-safe -- icl_embed_file decodes on its callers' threads concurrently)
+    struct crc_table {
+        uint32_t t[256];
+    };
+    static const crc_table tab = [] {
+        crc_table x;
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            x.t[i] = c;
         }
-        init = true;
-    }
+        return x;
+    }();
+    const uint32_t *table = tab.t;
     uint32_t c = 0xffffffffu;
     for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
     return c ^ 0xffffffffu;

@@ -1545,7 +1545,17 @@ int icl_embed_dev_locked(icl_ctx *ctx, const uint8_t *d_img, int64_t n, int head
                                              : forward_batch<F32>(ctx, prec, d_img + i * ICL_IMG_BYTES, B, head, d_out + i * head, lane, strm);
         if (rc) return rc;
         ICL_HIP(ctx, hipEventRecord(ev, strm));
-        if (ctx->embed_hook) ICL_TRY(ctx->embed_hook(i, B, ev)); // rows [i, i + B) of d_out are complete once ev has fired
+        if (ctx->embed_hook) { // rows [i, i + B) of d_out are complete once ev has fired
+            const int hrc = ctx->embed_hook(i, B, ev);
+            if (hrc) { // (leave the lanes the way a completed loop does: no launch stream left selected, the side streams joined)
+                ctx->cur_stream = nullptr;
+                for (int l = 1; l < lanes; ++l) {
+                    hipEvent_t ej = l == 1 ? ctx->ev_join : ctx->model->xjoin[l];
+                    if (hipEventRecord(ej, lane_stream(l)) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, ej, 0);
+                }
+                return hrc;
+            }
+        }
     }
     ctx->cur_stream = nullptr;
     for (int l = 1; l < lanes; ++l) { // join
@@ -1734,7 +1744,7 @@ static int read_ppm(icl_ctx *ctx, const char *path, std::vector<uint8_t> &rgb, i
         ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
     }
     fclose(f);
-    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only JPEG (Huffman), PNG (non-interlaced) and binary PPM (P6, maxval 255) are decoded by this build", path);
+    if (!ok) return icl_fail(ctx, ICL_ERR_IO, "failed to read image: %s. Only JPEG (Huffman; baseline or progressive), PNG and binary PPM (P6, maxval 255) are decoded by this build", path);
     return ICL_OK;
 }
 

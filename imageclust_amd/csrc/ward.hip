@@ -4411,8 +4411,10 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // ResNet embeddings: 5.3 M entries (0.11 % of the pairs) at margin 3, 5.4 M at 15, 323 M (6.5 %, distance stage 0.2 -> 1.4 s) at 63;
         // the merge loop then still needs 8 213 rounds (1.4 per step, 8 652 entries) for rows whose near neighbours are all gone
         rf_init.margin = 3.0f;
-        const int blocks = (int)std::min<int64_t>(n, 256 * 64);
-        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3(blocks), dim3(n > 4096 ? 1024 : 256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, w->msz, w->mcid,
+        // 256 threads at every size (1 024 above n = 4096 until round 4): a row costs one pass + one round of exact evaluations -- chains of D
+        // dependent additions, ~12 us whatever their number --, so the kernel is bound by rows in flight per CU, not by a row's scan rate
+        // (dist_ms at N = 100 000: 187 -> 174 ms)
+        hipLaunchKernelGGL(row_argmin_tri_kernel, dim3((int)std::min<int64_t>(n, 256 * 256)), dim3(256), 0, ctx->stream, w->Dtri, w->rowoff, w->asz, w->msz, w->mcid,
                            max_size, n, w->rowmin, w->rownn, rf_init);
         ICL_HIP(ctx, hipGetLastError());
     }
@@ -4879,8 +4881,15 @@ extern "C" int icl_embed_cluster_dev(icl_ctx *ctx, const uint8_t *d_img, int64_t
         }
         return ICL_OK;
     };
-    int rc = icl_embed_dev_locked(ctx, d_img, n, d, prec, d_E);
-    ctx->embed_hook = nullptr;
+    struct hook_guard { // the hook captures this frame's locals: never leave it installed, whatever way the embed call ends
+        icl_ctx *c;
+        ~hook_guard() { c->embed_hook = nullptr; }
+    };
+    int rc;
+    {
+        hook_guard hg{ctx};
+        rc = icl_embed_dev_locked(ctx, d_img, n, d, prec, d_E);
+    }
     if (rc == ICL_OK && next_tr != ntr) rc = icl_fail(ctx, ICL_ERR_HIP, "icl_embed_cluster_dev: %lld of %lld distance tile rows were launched", (long long)next_tr, (long long)ntr);
     hipError_t e = hipEventRecord(ctx->ev_s3, s3);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_s3, 0);
