@@ -1,0 +1,38 @@
+"""Randomised sweep of the Lance-Williams bound rows (ICL_DIST_LWBOUND forced) against ward_fast.c: sizes, dimensions, constraints, data shapes.
+python scratch/lb_sweep.py [--cases 40] [--seed 1]"""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imageclust_amd import _lib
+from oracle import oracle as O
+from tests import ward_cases as WC
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=40)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+ctx = _lib.Context(0)
+bad = 0
+t_start = time.time()
+for case in range(a.cases):
+    kind, E, mn, mx = WC.random_case(rng)
+    n, d = E.shape
+    f = O.cluster_fast(E, mn, mx, lazy_ban=False)
+    res = []
+    for mode in (4, 2):
+        ctx.set_ward_options(mode)
+        try:
+            cid, rank, nc = ctx.cluster(E, mn, mx)
+            m = ctx.last_merges(); v = ctx.last_merge_values()
+            ok = (f["ok"] and np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"]) and nc == f["n_clusters"] and len(m) == f["merges"]
+                  and np.array_equal(m, f["log"][:, 2:4].astype(np.int32)) and np.array_equal(v.view(np.uint32), f["vals"].view(np.uint32)))
+        except _lib.ICLError as e:
+            ok = (not f["ok"])
+            if not ok:
+                print("   engine error:", e)
+        res.append(ok)
+    st = ctx.last_ward_stats()
+    print("case %2d %-8s n=%5d d=%5d min=%d max=%4d  lb rows %s  exact rows %s  (merges %d, steps %d)" % (case, kind, n, d, mn, mx, "OK" if res[0] else "MISMATCH", "OK" if res[1] else "MISMATCH", st["merges"], st["steps"]), flush=True)
+    bad += (not res[0]) + (not res[1])
+print("%d mismatches in %d cases, %.0f s" % (bad, a.cases, time.time() - t_start))
+sys.exit(1 if bad else 0)

@@ -324,6 +324,30 @@ def test_lance_williams_bound_rows_on_every_small_case_and_the_adversarial_batch
         ctx.set_ward_options(0)
 
 
+def test_randomised_sweep_bound_rows_and_exact_rows_against_the_oracle(ctx):
+    """60 random inputs (tests/ward_cases.py random_case: sizes 300-6000, D 4-2048, five data shapes incl. exact ties, duplicates, a large common
+    offset, heavy tails; min 1-5, max min..1000, unsatisfiable constraints included) through both ways of filling a new cluster's row, each against
+    ward_fast.c: ids, member order, merge log, every merge value.  (scratch/lb_sweep.py ran 440 such cases in round 4: no mismatch.)"""
+    rng = np.random.default_rng(20250218)
+    for case in range(60):
+        kind, E, mn, mx = WC.random_case(rng)
+        f = O.cluster_fast(E, mn, mx, lazy_ban=False)
+        for mode in (4, 2):
+            ctx.set_ward_options(mode)
+            try:
+                where = "case %d (%s, n=%d, d=%d, min=%d, max=%d), ward mode %d" % (case, kind, E.shape[0], E.shape[1], mn, mx, mode)
+                if not f["ok"]:
+                    with pytest.raises(Exception):
+                        ctx.cluster(E, mn, mx)
+                    continue
+                cid, rank, nc = ctx.cluster(E, mn, mx)
+                assert np.array_equal(cid, f["cluster_id"]) and np.array_equal(rank, f["member_rank"]) and nc == f["n_clusters"], where
+                assert np.array_equal(ctx.last_merges(), f["log"][:, 2:4].astype(np.int32)), where
+                assert np.array_equal(ctx.last_merge_values().view(np.uint32), f["vals"].view(np.uint32)), where
+            finally:
+                ctx.set_ward_options(0)
+
+
 def test_exact_rows_and_bound_rows_agree_with_the_oracle_at_n24000(ctx):
     """The two ways the exact mode fills a new cluster's row -- 3 D unfused operations per entry (ICL_DIST_BOUND) and Lance-Williams
     lower bounds evaluated on demand (ICL_DIST_LWBOUND, what auto picks here) -- on one multi-block input against ward_fast.c."""

@@ -67,3 +67,30 @@ def small_cases():
     for n, mn, mx in [(100, 1, 1), (100, 1, 2), (101, 1, 2), (37, 1, 3), (64, 5, 64)]:
         out.append(("target_%d_%d_%d" % (n, mn, mx), mog(n, 16, n), mn, mx))
     return out
+
+
+def random_case(rng):
+    """One input of the randomised sweeps (scratch/lb_sweep.py, test_randomised_sweep_*): size, dimension (multiples of 4: the Lance-Williams bound
+    rows need whole k-groups), data shape and constraints drawn at random.  Shapes: mixture of Gaussians; non-negative features with a large common
+    mean and a small spread (ResNet-like, and worse); integer grids (exact ties, duplicates); rank 3; heavy tails."""
+    n = int(rng.choice([300, 900, 1500, 2500, 4200, 6000]))
+    d = int(rng.choice([4, 8, 16, 64, 128, 512, 2048]))
+    if d == 2048 and n > 2500:
+        n = 2500
+    kind = str(rng.choice(["mog", "offset", "grid", "lowrank", "heavy"]))
+    if kind == "mog":
+        k = max(n // int(rng.choice([5, 20, 60])), 1)
+        cen = rng.standard_normal((k, d)).astype(np.float32)
+        E = cen[rng.integers(0, k, n)] + np.float32(rng.choice([0.02, 0.1, 0.5])) * rng.standard_normal((n, d)).astype(np.float32)
+    elif kind == "offset":
+        E = (np.float32(rng.choice([5.0, 50.0])) + np.abs(rng.standard_normal((1, d))).astype(np.float32)
+             + np.float32(rng.choice([1e-3, 0.05])) * rng.standard_normal((n, d)).astype(np.float32))
+    elif kind == "grid":
+        E = rng.integers(0, int(rng.choice([2, 3, 6])), (n, d)).astype(np.float32)
+    elif kind == "lowrank":
+        E = (rng.standard_normal((n, 3)) @ rng.standard_normal((3, d))).astype(np.float32)
+    else:
+        E = (rng.standard_normal((n, d)) * np.exp(2.0 * rng.standard_normal((n, 1)))).astype(np.float32)
+    mn = int(rng.choice([1, 2, 5]))
+    mx = max(int(rng.choice([mn, mn + 1, 6, 50, 1000])), mn)
+    return kind, np.ascontiguousarray(E, np.float32), mn, mx
