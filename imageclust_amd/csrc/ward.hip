@@ -3310,8 +3310,9 @@ __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64
         st->B.dbg4[3] = ~0ull;
     })
     {
-        constexpr int NW = (int)(sizeof(ward_state) / 4);
-        static_assert(sizeof(ward_state) % 4 == 0, "snapshot by dwords");
+        // (the spare workgroups' phase-A tables -- flags, matched rows, key streams: 12 of the state's 15 KB, last in the struct -- are not read here)
+        constexpr int NW = (int)((offsetof(ward_state, B) + offsetof(ward_batch_state, pa_flag)) / 4);
+        static_assert((offsetof(ward_state, B) + offsetof(ward_batch_state, pa_flag)) % 4 == 0, "snapshot by dwords");
         for (int q = threadIdx.x; q < NW; q += WB_FIN_THREADS) reinterpret_cast<int *>(&ls)[q] = reinterpret_cast<const int *>(st)[q];
         if (threadIdx.x == 0) npk = 0;
     }
