@@ -9,6 +9,7 @@ from tests import ward_cases as WC
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--large", action="store_true", help="N = 12 000 ... 40 000 (several 64-cluster blocks per workgroup, creation ids past 65 536), D = 8 ... 128")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 ctx = _lib.Context(0)
@@ -16,6 +17,17 @@ bad = 0
 t_start = time.time()
 for case in range(a.cases):
     kind, E, mn, mx = WC.random_case(rng)
+    if a.large:
+        n = int(rng.choice([12000, 20000, 30000, 40000])); d = int(rng.choice([8, 32, 128]))
+        k = max(n // int(rng.choice([5, 20, 60])), 1)
+        if kind in ("grid",):
+            E = rng.integers(0, 4, (n, d)).astype(np.float32)
+        elif kind == "offset":
+            E = (np.float32(20.0) + np.abs(rng.standard_normal((1, d))) + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+        else:
+            E = (rng.standard_normal((k, d))[rng.integers(0, k, n)] + 0.1 * rng.standard_normal((n, d))).astype(np.float32)
+        E = np.ascontiguousarray(E, np.float32)
+        mn, mx = int(rng.choice([1, 3, 5])), int(rng.choice([6, 50, 1000]))
     n, d = E.shape
     f = O.cluster_fast(E, mn, mx, lazy_ban=False)
     res = []

@@ -327,7 +327,7 @@ def test_lance_williams_bound_rows_on_every_small_case_and_the_adversarial_batch
 def test_randomised_sweep_bound_rows_and_exact_rows_against_the_oracle(ctx):
     """60 random inputs (tests/ward_cases.py random_case: sizes 300-6000, D 4-2048, five data shapes incl. exact ties, duplicates, a large common
     offset, heavy tails; min 1-5, max min..1000, unsatisfiable constraints included) through both ways of filling a new cluster's row, each against
-    ward_fast.c: ids, member order, merge log, every merge value.  (scratch/lb_sweep.py ran 440 such cases in round 4: no mismatch.)"""
+    ward_fast.c: ids, member order, merge log, every merge value.  (scratch/lb_sweep.py ran 1 240 such cases and 12 at N = 12 000 ... 40 000 in round 4: no mismatch.)"""
     rng = np.random.default_rng(20250218)
     for case in range(60):
         kind, E, mn, mx = WC.random_case(rng)
