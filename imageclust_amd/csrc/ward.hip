@@ -854,7 +854,7 @@ __device__ __forceinline__ void block_min3(float &tv, int &ti, float &ub, float 
 
 __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t len, const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                              int my_id, int my_size, int max_size, const int *ex, int nex, float &bv, int &bi, float *sv, int *si,
-                                             const wrefine rf, float tv0, int ti0, float thr0, float *scr)
+                                             const wrefine rf, float tv0, int ti0, float thr0, float *scr, const uint32_t *__restrict__ mpk = nullptr)
 {
     // scr: 256 floats of LDS per wave of the workgroup (ward_sqdist_wave's scratch), 16-byte aligned
     // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
@@ -902,6 +902,51 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
         if (rf.stat && threadIdx.x == 0) atomicAdd(&rf.stat[1], 1ull);
         __syncthreads();
         // pass B: flagged entries whose lower bound does not exceed the threshold
+        if (mpk) {
+            // on the packed column words, one test per column with selects only (|entry| bits <= threshold bits: both are non-negative floats);
+            // the exclusion list and the append sit behind the rare hit.  (The visitor below reads three streams and branches per column:
+            // a collecting pass cost a merged row ~40 us on top of its first pass, and one such row per launch is the launch's tail.)
+            const int szb = wpk_bits(max_size);
+            const uint32_t smask = (1u << szb) - 1u;
+            const uint32_t thr_bits = thr_b >= 0.0f ? __float_as_uint(thr_b) : 0u; // (NaN / negative: nothing qualifies, as in the comparison below)
+            const bool thr_ok = thr_b >= 0.0f;
+            const int64_t nvec = len >> 2;
+            auto hit = [&](float v, uint32_t k) -> bool {
+                const int m = (int)(k & smask), c = (int)(k >> szb);
+                const uint32_t vb = __float_as_uint(v);
+                return (m > 0) & (m + my_size <= max_size) & (c < my_id) & ((vb >> 31) != 0) & ((vb & 0x7fffffffu) <= thr_bits) & thr_ok;
+            };
+            auto take = [&](uint32_t k, int col) {
+                if (!excluded((int)(k >> szb))) {
+                    const int at = atomicAdd(&ref_cnt, 1);
+                    if (at < WB_REF_CAP) ref_col[at] = col;
+                }
+            };
+            for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
+                float4 v[WB_SCAN_U];
+                uint4 k[WB_SCAN_U];
+#pragma unroll
+                for (int j = 0; j < WB_SCAN_U; ++j) {
+                    const int64_t q = q0 + (int64_t)j * blockDim.x;
+                    const bool has = q < nvec;
+                    v[j] = has ? reinterpret_cast<const float4 *>(row)[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    k[j] = has ? reinterpret_cast<const uint4 *>(mpk)[q] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < WB_SCAN_U; ++j) {
+                    const bool h0 = hit(v[j].x, k[j].x), h1 = hit(v[j].y, k[j].y), h2 = hit(v[j].z, k[j].z), h3 = hit(v[j].w, k[j].w);
+                    if (h0 | h1 | h2 | h3) {
+                        const int col = (int)((q0 + (int64_t)j * blockDim.x) * 4);
+                        if (h0) take(k[j].x, col);
+                        if (h1) take(k[j].y, col + 1);
+                        if (h2) take(k[j].z, col + 2);
+                        if (h3) take(k[j].w, col + 3);
+                    }
+                }
+            }
+            for (int64_t q = nvec * 4 + threadIdx.x; q < len; q += blockDim.x)
+                if (hit(row[q], mpk[q])) take(mpk[q], (int)q);
+        } else
         ward_row_visit(row, len, msz, mcid, [&](float v, int m, int c, int col) {
             if (!(m > 0 && m + my_size <= max_size && c < my_id) || !wflagged(v)) return;
             if (fabsf(v) <= thr_b && !excluded(c)) {
@@ -1225,12 +1270,12 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
             bi = ti;
             return;
         }
-        scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, scr);
+        scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, tv, scr, mpk);
         return;
     }
     const float up = (my_id < rf.n && mcid[lc] < rf.n) ? wupper(lv, rf.nrm[my_id] + rf.nrm[mcid[lc]], rf) : ICL_MAXF;
     const float thr = (up < tv) ? up : tv; // (a NaN / +inf upper bound -- overflowing norms -- leaves the best value, possibly MaxFloat32)
-    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, scr);
+    scan_row_refine(row, len, msz, mcid, my_id, my_size, max_size, ex, nex, bv, bi, sv, si, rf, tv, ti, thr, scr, mpk);
 }
 
 // Initial row caches: one workgroup per singleton row r (columns 0..r-1).
