@@ -58,6 +58,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #else
 #define WB_TIMER(stmt)
 #endif
+#define WB_KMAX 32 /* capacity of the batch tables in the device state (the bound-rows loop may use more picks per step than the exact-rows loop's WB_K) */
 #define WB_K 16 /* merges attempted per batched step (a power of two: lane-indexed tables): N=100k takes 15.6 merges per step */
 #ifndef WB_R
 #define WB_R 64 /* workgroups that re-minimise rows whose cached partner is a member of the batch (<= 64: one lane each in their flag barrier).  48 until the
@@ -94,11 +95,11 @@ __device__ __forceinline__ void wb_acquire() { __builtin_amdgcn_fence(__ATOMIC_A
 #define WB_MAXWAVES (128 / (WB_WPOP + 1)) /* waves of a workgroup that runs ward_spec_rescan: its merge holds two entries per lane */
 struct ward_batch_state {
     int32_t nb;                                   // tentative picks whose rows the update kernel is computing
-    int32_t a[WB_K], b[WB_K], sa[WB_K], sb[WB_K]; // pair (a = higher creation id), sizes
-    float val[WB_K];                              // Ward value of the pair
+    int32_t a[WB_KMAX], b[WB_KMAX], sa[WB_KMAX], sb[WB_KMAX]; // pair (a = higher creation id), sizes
+    float val[WB_KMAX];                           // Ward value of the pair
     int32_t pre_n, pre_for_nb;                    // preselection (assumes the nb picks above all commit)
-    int32_t pre_row[WB_K], pre_nn[WB_K], pre_sa[WB_K], pre_sb[WB_K];
-    float pre_val[WB_K];
+    int32_t pre_row[WB_KMAX], pre_nn[WB_KMAX], pre_sa[WB_KMAX], pre_sb[WB_KMAX];
+    float pre_val[WB_KMAX];
     int32_t ov_n, ov_pad;                         // rows re-minimised under the "batch commits" assumption
     int32_t ov_row[8], ov_nn[8];
     float ov_val[8];
@@ -110,8 +111,8 @@ struct ward_batch_state {
     int32_t why[4];                               // ... because: 0 truncated batch, 1 preselection stale/empty, 2 new row first / forwarding chain
     unsigned long long sum_live, sum_live_nb;     // sum over steps of live clusters (x picks)
     unsigned long long sum_dep;                   // sum over steps of rows whose cached partner is a member of the batch
-    unsigned long long ckey[WB_K];                // per tentative new row: (value bits << 32 | column) minimum
-    unsigned long long ckey2[WB_K];               // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
+    unsigned long long ckey[WB_KMAX];             // per tentative new row: (value bits << 32 | column) minimum
+    unsigned long long ckey2[WB_KMAX];            // the same minimum WITHOUT the batch's members: the row's cache if the whole batch commits
 #ifdef ICL_WARD_TIMERS
     unsigned long long dbg[8], dbg_t0, dbg2[3], dbg3[4], dbg4[4], dbg5[4], dbg6[8]; // in-kernel stage timers
     unsigned long long rf_stat[8];   // distance bounds: scans that found a bound on top, collecting passes, evaluation rounds, entries evaluated: [0..3] merge loop, [4..7] initial row minima
@@ -159,7 +160,8 @@ struct icl_ward_ws {
     uint32_t *mpk = nullptr;   // [ld] by column: (mcid << bits(max_size)) | msz, the row scans' one-word view of msz + mcid
     int32_t *msz = nullptr;    // [ld] by column: size of the occupant if alive else 0
     int32_t *mcid = nullptr;   // [ld] by column: creation id of the occupant
-    float *Dtri = nullptr;     // (N + WB_K) rows x ld floats
+    float *Dtri = nullptr;     // (N + WB_KMAX) rows x ld floats
+    int32_t *pkrec = nullptr;  // bound-rows loop: the picks of the next batch for ward_data_lb_kernel
     int64_t ld = 0;            // row pitch in floats (N rounded up to 64)
     float *nrm = nullptr;      // [capN] |E[r] - mu|^2 of the singletons: the scans' upper bounds of flagged entries (distance bounds)
     double *colsum = nullptr;  // [capD] column sums of E
@@ -190,7 +192,7 @@ void icl_ward_free(icl_ctx *ctx)
     icl_ward_ws *w = ctx->ward;
     if (!w) return;
     void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mpk};
+                    w->Dtri, w->merges, w->st, w->fc_min, w->fc_nn, w->fc_out, w->nrm, w->colsum, w->zero, w->mpk, w->pkrec};
     if (w->graph_exec) (void)hipGraphExecDestroy(w->graph_exec);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -752,7 +754,7 @@ __device__ __forceinline__ float ward_scale(float s, int sx, int sy)
 // centroid and size of cluster `id` for an exact evaluation: singletons straight from E, merged clusters (only in rows of lb mode) from Crow
 __device__ __forceinline__ const float *wcent(const wrefine &rf, int id)
 {
-    return id < rf.n ? rf.E + (int64_t)id * rf.d : rf.Crow + (int64_t)rf.id_slot[id] * rf.d;
+    return id < rf.n ? rf.E + (int64_t)id * rf.d : rf.Crow + (int64_t)id * rf.d; // (bound-rows loop: Crow is indexed by creation id)
 }
 __device__ __forceinline__ int wsize(const wrefine &rf, int id) { return id < rf.n ? 1 : rf.asz[id]; }
 
@@ -1360,7 +1362,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
         rowmin[i] = ICL_MAXF;
         rownn[i] = -1;
         mcol[i] = i < n ? (int32_t)i : -1;        // a merged cluster inherits its parent's column when its merge commits
-        rowoff[i] = i < n + WB_K ? i * ld : 0;    // singletons and the WB_K spare rows; later clusters: set when they are picked
+        rowoff[i] = i < n + WB_KMAX ? i * ld : 0; // singletons and the spare rows; later clusters: set when they are picked
     }
     if (i < ld) {
         msz[i] = i < n ? 1 : 0;
@@ -1389,7 +1391,7 @@ __global__ void ward_init_kernel(int64_t n, int64_t S, int64_t M, int64_t ld, in
         st->B.dirty_n = 0;
         st->B.ov_n = 0;
         for (int j = 0; j < WB_R; ++j) st->B.spec_done[j] = st->B.pa_flag[j] = 0;
-        for (int j = 0; j < WB_K; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
+        for (int j = 0; j < WB_KMAX; ++j) st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
         st->B.blk_next = 0;
 #ifdef ICL_WARD_TIMERS
         for (int j = 0; j < 8; ++j) st->B.dbg[j] = 0;
@@ -3144,7 +3146,8 @@ __global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__res
 #ifndef WL_THREADS
 #define WL_THREADS 768
 #endif
-#define WL_SLOTS 256 /* live clusters per main workgroup of ward_update_lb_kernel */
+#define WL_SLOTS 256 /* creation ids per main workgroup of ward_update_lb_kernel */
+#define WL_K 16      /* picks per step of the bound-rows loop */
 // update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
 // the pairs of clusters created by this batch, then one lane per live cluster.
 __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
@@ -3221,11 +3224,12 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     // a workgroup takes WL_SLOTS live clusters; its WL_THREADS / WL_SLOTS thread groups share the picks (group g: picks g, g + 3, ...): a third of
     // the scattered reads per CU, three times the CUs (72 workgroups of 768 lanes at 55 000 live clusters held the launch for 74 us)
     constexpr int NG = WL_THREADS / WL_SLOTS;
+    // (the bound-rows loop keeps no slot table: a workgroup takes WL_SLOTS creation ids, dead ones drop out after one load)
     const int64_t slot0 = ((int64_t)blockIdx.x - (WB_R + 2)) * WL_SLOTS;
-    if (slot0 >= nlive) return;
+    if (slot0 >= n + t) return;
     const int sub = (int)threadIdx.x / WL_SLOTS;
     const int64_t slot = slot0 + (int)threadIdx.x % WL_SLOTS;
-    const int x = slot < nlive && slot < S ? slot_id[slot] : -1;
+    const int x = slot < n + t ? (int)slot : -1;
     const int sx = x >= 0 ? asz[x] : 0;
     const bool live = x >= 0 && sx > 0;
     const int64_t rx = live ? rowoff[x] : 0;
@@ -3277,6 +3281,307 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[1] += wall_clock64() - tm0;) // "main0": main block 0, whole
 }
 
+#define WB_FIN_THREADS 512
+// Row storage of the cluster that merge q will create, K spare rows (ward_new_row below, for a batch width of K)
+template <int K>
+__device__ __forceinline__ int64_t ward_new_row_k(int64_t n, int64_t ld, int q, int t0, const int32_t *a0, const int32_t *merges, const int64_t *rowoff)
+{
+    if (q < K) return (n + q) * ld;
+    const int p = q - K;
+    const int a = p >= t0 ? a0[p - t0] : merges[3 * p];
+    return rowoff[a];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// finish of the bound-rows loop (ward_update_lb_kernel).  The same contract as ward_finish_batch_kernel below -- validate and commit
+// the longest valid prefix of the tentative picks (MergeClusters / RemoveClusters bookkeeping, clustering.go:29-58,:240-241), install
+// the rows the spare workgroups re-minimised, take the next batch from the preselection -- without what only the exact rows need:
+//  * no slot table.  Centroids are kept by CREATION ID (Crow[id]); they are only read by exact evaluations, and a cluster's id is known
+//    when it is PICKED (n + t + j), so the merged centroid of a pick is written once, at pick time, by ward_data_lb_kernel; a pick that
+//    is rolled back leaves a row that the id's next owner overwrites.
+//  * a new row is never a pick (its cache is a lower bound): the next batch is the leading part of the preselected list whose values
+//    do not exceed the smallest bound of the rows just created -- old rows win ties, clustering.go:123-131 -- or, when that is empty
+//    (truncated batch, stale preselection, a new row first), ONE pick by the lazy selection over all row caches, which re-minimises
+//    whatever it finds stale, bound rows included.  The members of the picks are old, clean clusters: never created by this step.
+// pkrec: [0] picks, then (a, b, size a, size b, new id) each.
+// ------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_lb_kernel(int64_t n, int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
+                                                                       int32_t *__restrict__ merges, float *__restrict__ Dtri, int64_t *__restrict__ rowoff,
+                                                                       int32_t *__restrict__ mcol, int32_t *__restrict__ msz, int32_t *__restrict__ mcid, int64_t ld,
+                                                                       int max_size, ward_state *__restrict__ st, int32_t *__restrict__ pkrec, const wrefine rf,
+                                                                       uint32_t *__restrict__ mpk)
+{
+    static_assert(K <= WB_KMAX && K <= 32, "one lane per pick, state tables of WB_KMAX entries");
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int sh[8];
+    __shared__ ward_state ls; // snapshot of the state at kernel entry
+    __shared__ int pk_a[K], pk_b[K], pk_sa[K], pk_sb[K], npk;
+    __shared__ float pk_v[K];
+    __shared__ __attribute__((aligned(16))) float fin_scr[WB_FIN_THREADS / 64][256]; // ward_sqdist_wave's scratch
+    WB_TIMER(const unsigned long long tf0 = wall_clock64();)
+    WB_TIMER(if (threadIdx.x == 0 && st->B.dbg3[3] && st->B.dbg4[3] != ~0ull) {
+        st->B.dbg4[0] += st->B.dbg3[3] - st->B.dbg4[3]; /* first main start -> last main end */
+        st->B.dbg4[1] += tf0 - st->B.dbg3[3];           /* last main end -> finish start */
+        if (st->B.dbg5[0] > st->B.dbg_t0) st->B.dbg5[1] += st->B.dbg5[0] - st->B.dbg_t0; /* preselection start -> last spare workgroup's end */
+        if (st->B.dbg6[0] > st->B.dbg_t0) st->B.dbg6[1] += st->B.dbg6[0] - st->B.dbg_t0; /* preselection start -> last end of the spare phase A */
+        st->B.dbg6[0] = 0;
+        st->B.dbg5[0] = 0;
+        st->B.dbg3[3] = 0;
+        st->B.dbg4[3] = ~0ull;
+    })
+    {
+        constexpr int NW = (int)((offsetof(ward_state, B) + offsetof(ward_batch_state, pa_flag)) / 4);
+        for (int q = threadIdx.x; q < NW; q += WB_FIN_THREADS) reinterpret_cast<int *>(&ls)[q] = reinterpret_cast<const int *>(st)[q];
+        if (threadIdx.x == 0) {
+            npk = 0;
+            pkrec[0] = 0;
+        }
+    }
+    __syncthreads();
+    if (ls.done) return;
+    const int nbp = ls.B.nb, t0 = ls.t, nlive0 = ls.nlive, target = ls.target;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        // ---- (1) validate: the longest prefix in which no pair of an earlier new cluster can precede the pick (lower bounds of the new rows' minima)
+        int J = nbp;
+        {
+            float cm = ICL_MAXF;
+            if (lane < nbp) {
+                const unsigned long long k = ls.B.ckey[lane < WB_KMAX ? lane : 0];
+                if (k != ~0ull) cm = __uint_as_float((unsigned)(k >> 32));
+            }
+            float pm = __shfl_up(cm, 1, 64); // exclusive prefix minimum
+            if (lane == 0) pm = ICL_MAXF;
+#pragma unroll
+            for (int off = 1; off < K; off <<= 1) {
+                const float o = __shfl_up(pm, off, 64);
+                if (lane >= off) pm = fminf(pm, o);
+            }
+            const bool bad = lane >= 1 && lane < nbp && pm < ls.B.val[lane < WB_KMAX ? lane : 0];
+            const unsigned long long bm = __ballot(bad);
+            if (bm) J = __ffsll((long long)bm) - 1;
+        }
+        if (lane == 0) sh[0] = J;
+        const bool full0 = J == nbp && ls.B.pre_for_nb == nbp && nbp > 0;
+        // ---- (2) commit
+        if (lane < J) {
+            const int j = lane;
+            const int a = ls.B.a[j], b = ls.B.b[j], c = (int)(n + t0 + j);
+            const unsigned long long key = J == nbp ? ls.B.ckey2[j] : ls.B.ckey[j]; // full commit: the batch's members are all gone
+            merges[3 * (t0 + j)] = a;
+            merges[3 * (t0 + j) + 1] = b;
+            merges[3 * (t0 + j) + 2] = (int)__float_as_uint(ls.B.val[j]); // the pair's Ward distance: the dendrogram height
+            asz[a] = 0;
+            asz[b] = 0;
+            asz[c] = ls.B.sa[j] + ls.B.sb[j];
+            const int ca = mcol[a], cb = mcol[b]; // recycled storage: c takes over a's column, b's column dies
+            mcol[c] = ca;
+            msz[ca] = ls.B.sa[j] + ls.B.sb[j];
+            mcid[ca] = c;
+            msz[cb] = 0;
+            if (mpk) {
+                mpk[ca] = ((uint32_t)c << wpk_bits(max_size)) | (uint32_t)(ls.B.sa[j] + ls.B.sb[j]);
+                mpk[cb] = 0u;
+            }
+            rowmin[a] = ICL_MAXF;
+            rowmin[b] = ICL_MAXF;
+            rowmin[c] = key == ~0ull ? ICL_MAXF : __uint_as_float((unsigned)(key >> 32));
+            rownn[c] = key == ~0ull ? -1 : WB_NN_BOUND; // a lower bound of the row's minimum: re-minimised before it can be a pick
+        }
+        if (full0 && lane < ls.B.ov_n) { // rows re-minimised by the preselection without the (now dead) members
+            rowmin[ls.B.ov_row[lane]] = ls.B.ov_val[lane];
+            rownn[ls.B.ov_row[lane]] = ls.B.ov_nn[lane];
+        }
+        if (J == nbp && J > 0 && lane < WB_R && ls.B.spec_done[lane] == ls.B.epoch) { // ... and by the spare workgroups
+#pragma unroll
+            for (int m = 0; m < WB_RM; ++m) {
+                const int sr = ls.B.spec_row[m * WB_R + lane];
+                if (sr >= 0) {
+                    rowmin[sr] = ls.B.spec_val[m * WB_R + lane];
+                    rownn[sr] = ls.B.spec_nn[m * WB_R + lane];
+                }
+            }
+        }
+        if (lane == 0 && J > 0) {
+            st->nlive = nlive0 - J;
+            st->t = t0 + J;
+            st->B.steps = ls.B.steps + 1;
+            st->B.commits = ls.B.commits + J;
+        }
+        // ---- (3) the next batch out of the preselection: its leading pairs whose value does not exceed any new row's bound
+        const int t1 = t0 + J, pn0 = ls.B.pre_n;
+        int np = 0;
+        if (full0 && t1 < target && pn0 > 0) {
+            float cmin = ICL_MAXF;
+            if (lane < J) {
+                const unsigned long long key = ls.B.ckey[lane];
+                if (key != ~0ull) cmin = __uint_as_float((unsigned)(key >> 32));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, off, 64));
+            const bool safe = lane < pn0 && lane < K && ls.B.pre_val[lane < WB_KMAX ? lane : 0] <= cmin; // (sorted: a prefix)
+            const int nsafe = __popcll(__ballot(safe));
+            np = nsafe < target - t1 ? nsafe : target - t1;
+            if (lane < np) {
+                pk_a[lane] = ls.B.pre_row[lane];
+                pk_b[lane] = ls.B.pre_nn[lane];
+                pk_sa[lane] = ls.B.pre_sa[lane];
+                pk_sb[lane] = ls.B.pre_sb[lane];
+                pk_v[lane] = ls.B.pre_val[lane];
+            }
+        }
+        if (lane == 0) {
+            npk = np;
+            if (np == 0 && nbp > 0) { // why no batch: 0 truncated, 1 preselection stale / empty, 2 a new row first
+                const int why = J != nbp ? 0 : (ls.B.pre_for_nb != nbp || pn0 <= 0) ? 1 : 2;
+                st->B.why[why] = ls.B.why[why] + 1;
+                st->B.general = ls.B.general + 1;
+            }
+        }
+    }
+    __syncthreads();
+    const int J = sh[0];
+    const int t = t0 + J;
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[3] += wall_clock64() - tf0;)
+    if (t >= target) {
+        if (threadIdx.x == 0) st->B.nb = 0; // len(clusters) == nClusters: the reference loop has ended (clustering.go:220)
+        return;
+    }
+    if (npk == 0) {
+        // ONE pick by the lazy selection over all rows (first step, truncated batch, stale preselection, a new row first)
+        const int64_t nvec = (n + t + 3) >> 2;
+        float bv;
+        int bi;
+        for (;;) {
+            bv = ICL_MAXF;
+            bi = -1;
+            for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += 4 * (int64_t)blockDim.x) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t q = q0 + (int64_t)j * blockDim.x;
+                    v[j] = q < nvec ? reinterpret_cast<const float4 *>(rowmin)[q] : make_float4(ICL_MAXF, ICL_MAXF, ICL_MAXF, ICL_MAXF);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t q = q0 + (int64_t)j * blockDim.x;
+                    const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (e[i] < bv) {
+                            bv = e[i];
+                            bi = (int)(q * 4 + i);
+                        }
+                }
+            }
+            block_argmin(bv, bi, sv, si);
+            if (bi < 0) break;
+            if (threadIdx.x == 0) {
+                const int nn0 = rownn[bi];
+                sh[1] = (nn0 >= 0 && asz[nn0] > 0) ? 0 : 1; // (WB_NN_BOUND: never scanned)
+            }
+            __syncthreads();
+            const int dirty = sh[1];
+            __syncthreads();
+            if (!dirty) break;
+            float rv;
+            int ri;
+            {
+                const int noex[1] = {-1};
+                scan_row_min(Dtri + rowoff[bi], ward_row_len(bi, n), msz, mcid, bi, asz[bi], max_size, noex, 0, rv, ri, sv, si, rf, &fin_scr[0][0], mpk);
+            }
+            if (threadIdx.x == 0) {
+                rowmin[bi] = rv;
+                rownn[bi] = ri;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            st->B.slow = ls.B.slow + 1;
+            if (bi < 0) {
+                st->done = 1; // clustering.go:222-225 "No more clusters to merge."
+                st->B.nb = 0;
+            } else {
+                const int nn = rownn[bi];
+                pk_a[0] = bi;
+                pk_b[0] = nn;
+                pk_v[0] = bv;
+                pk_sa[0] = asz[bi];
+                pk_sb[0] = asz[nn];
+                npk = 1;
+            }
+        }
+        __syncthreads();
+        if (npk == 0) return;
+    }
+    // ---- (4) the batch record
+    const int np = npk;
+    if (threadIdx.x < K) {
+        const int j = threadIdx.x;
+        if (j < np) {
+            st->B.a[j] = pk_a[j];
+            st->B.b[j] = pk_b[j];
+            st->B.sa[j] = pk_sa[j];
+            st->B.sb[j] = pk_sb[j];
+            st->B.val[j] = pk_v[j];
+            st->B.ckey[j] = st->B.ckey2[j] = ~0ull;
+            rowmin[n + t + j] = ICL_MAXF; // rows being created are not selectable yet
+            rowoff[n + t + j] = ward_new_row_k<K>(n, ld, t + j, t0, ls.B.a, merges, rowoff);
+            pkrec[1 + 5 * j] = pk_a[j];
+            pkrec[2 + 5 * j] = pk_b[j];
+            pkrec[3 + 5 * j] = pk_sa[j];
+            pkrec[4 + 5 * j] = pk_sb[j];
+            pkrec[5 + 5 * j] = (int)(n + t + j);
+        }
+        if (j == 0) {
+            st->B.nb = np;
+            st->B.sum_live = ls.B.sum_live + (unsigned long long)(nlive0 - J);
+            st->B.sum_live_nb = ls.B.sum_live_nb + (unsigned long long)(nlive0 - J) * np;
+            st->B.epoch = ls.B.epoch + 1;
+            st->B.pre_n = 0;
+            st->B.ov_n = 0;
+            st->B.pre_for_nb = -1;
+            pkrec[0] = np;
+        }
+    }
+    WB_TIMER(if (threadIdx.x == 0) st->B.dbg[5] += wall_clock64() - tf0;)
+}
+
+// MergeClusters' centroid (clustering.go:37-40) of every pick of the next batch, straight into Crow[new id]: (float(sa) Ca + float(sb) Cb) / float(sa + sb),
+// each operation rounded.  grid (ceil(d / 4 / 256), K / 8): a thread owns one k-group of eight picks, all sixteen loads in flight.
+__global__ __launch_bounds__(256) void ward_data_lb_kernel(int d, float *__restrict__ Crow, const int32_t *__restrict__ pkrec)
+{
+    const int g = (int)(blockIdx.x * 256 + threadIdx.x), p0 = (int)blockIdx.y * 8, np = pkrec[0], dq = d >> 2;
+    if (g >= dq || p0 >= np) return;
+    float4 av[8], bv[8];
+    float fa[8], fb[8];
+    int cid[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int p = p0 + q < np ? p0 + q : p0; // (unused entries repeat a valid pick: straight-line code)
+        const int a = pkrec[1 + 5 * p], b = pkrec[2 + 5 * p];
+        fa[q] = (float)pkrec[3 + 5 * p];
+        fb[q] = (float)pkrec[4 + 5 * p];
+        cid[q] = pkrec[5 + 5 * p];
+        av[q] = reinterpret_cast<const float4 *>(Crow + (int64_t)a * d)[g];
+        bv[q] = reinterpret_cast<const float4 *>(Crow + (int64_t)b * d)[g];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (p0 + q >= np) break;
+        const float fs = (float)((int)fa[q] + (int)fb[q]);
+        float4 o;
+        { const float pa = fa[q] * av[q].x; const float pb = fb[q] * bv[q].x; const float sm = pa + pb; o.x = sm / fs; }
+        { const float pa = fa[q] * av[q].y; const float pb = fb[q] * bv[q].y; const float sm = pa + pb; o.y = sm / fs; }
+        { const float pa = fa[q] * av[q].z; const float pb = fb[q] * bv[q].z; const float sm = pa + pb; o.z = sm / fs; }
+        { const float pa = fa[q] * av[q].w; const float pb = fb[q] * bv[q].w; const float sm = pa + pb; o.w = sm / fs; }
+        reinterpret_cast<float4 *>(Crow + (int64_t)cid[q] * d)[g] = o;
+    }
+}
+
 // finish for a batch: (1) validate + commit the longest valid prefix of the tentative picks (bookkeeping of
 // MergeClusters / RemoveClusters, clustering.go:29-58,:240-241; centroid images into CT4 / Crow; slot compaction);
 // (2) choose the next batch from {rows just created} U {preselected old-row pairs}; (3) merged centroids (:37-40).
@@ -3320,7 +3625,6 @@ __device__ __forceinline__ int64_t ward_new_row(int64_t n, int64_t ld, int q, in
     return rowoff[a];
 }
 
-#define WB_FIN_THREADS 512
 __global__ __launch_bounds__(WB_FIN_THREADS) void ward_finish_batch_kernel(int64_t n, int d, int64_t S, float *__restrict__ CT, float *__restrict__ Crow,
                                                                 float *__restrict__ cnewK, int64_t cn_stride, int32_t *__restrict__ slot_id,
                                                                 int32_t *__restrict__ id_slot, int32_t *__restrict__ asz,
@@ -4059,7 +4363,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
     if (w->capN != n || w->capD != d) {
         // (re)allocate for exactly this shape
         void *ptrs[] = {w->CT, w->Crow, w->cnew, w->cnewI, w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->rowoff, w->mcol, w->msz, w->mcid,
-                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mpk};
+                        w->Dtri, w->merges, w->st, w->nrm, w->colsum, w->zero, w->mpk, w->pkrec};
+        w->pkrec = nullptr;
         w->nrm = nullptr;
         w->colsum = nullptr;
         w->zero = nullptr;
@@ -4077,7 +4382,7 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         w->M = 2 * n + 4; // creation ids: n singletons + at most n - 1 merged clusters (padded: rowmin is read in groups of four)
         w->M = (w->M + 3) / 4 * 4;
         w->ld = w->S; // row pitch: a multiple of 64 floats, so every row starts 256-byte aligned
-        w->dtri_floats = (n + WB_K) * w->ld;
+        w->dtri_floats = (n + WB_KMAX) * w->ld;
         const int64_t dd = d > 0 ? d : 1;
 #define WS_ALLOC(field, type, count)                                                                             \
     do {                                                                                                         \
@@ -4089,7 +4394,8 @@ static int ward_ensure(icl_ctx *ctx, int64_t n, int d)
         const int64_t ngrp = std::max<int64_t>(upd_groups((int)dd) + UPD_PAD_G, wb_groups((int)dd) + WB_PAD_G); // whole stages + prefetch slack
         WS_ALLOC(CT, float, 4 * ngrp * w->S);
         ICL_HIP(ctx, hipMemsetAsync(w->CT, 0, (size_t)(4 * ngrp * w->S) * sizeof(float), ctx->stream));
-        WS_ALLOC(Crow, float, dd * w->S);
+        WS_ALLOC(Crow, float, dd * std::max(w->S, w->M)); // by slot (exact rows) or by creation id (bound rows: no slot bookkeeping)
+        WS_ALLOC(pkrec, int32_t, 8 + 5 * WB_KMAX);
         w->cn_stride = 4 * std::max<int64_t>(ngrp, wb_groups((int)dd) + WB_PAD_G);
         WS_ALLOC(cnew, float, 16 * w->cn_stride); // 16 images whatever WB_K is: the update kernel's centroid pieces always cover 16 chains
         ICL_HIP(ctx, hipMemsetAsync(w->cnew, 0, (size_t)(16 * w->cn_stride) * sizeof(float), ctx->stream));
@@ -4527,6 +4833,12 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         // the express step's data phase runs in ward_finish_data_kernel from a record the finish kernel leaves behind cnewI
         int32_t *fdrec = (!lw && (d & 3) == 0) ? reinterpret_cast<int32_t *>(w->cnewI + 16 * w->cn_stride) : nullptr;
         auto finish_b = [&]() {
+            if (lbm) { // the bound-rows loop: no slot table, centroids by creation id
+                hipLaunchKernelGGL((ward_finish_lb_kernel<WL_K>), dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri,
+                                   w->rowoff, w->mcol, w->msz, w->mcid, w->ld, max_size, w->st, w->pkrec, rf, mpk);
+                hipLaunchKernelGGL(ward_data_lb_kernel, dim3((unsigned)icl_ceil_div(d >> 2, 256), WL_K / 8), dim3(256), 0, ctx->stream, d, w->Crow, w->pkrec);
+                return;
+            }
             hipLaunchKernelGGL(ward_finish_batch_kernel, dim3(1), dim3(WB_FIN_THREADS), 0, ctx->stream, n, d, w->S, w->CT, w->Crow, w->cnew, w->cn_stride,
                                w->slot_id, w->id_slot, w->asz, w->rowmin, w->rownn, w->merges, w->Dtri, w->rowoff, w->mcol, w->msz, w->mcid, w->ld, max_size,
                                w->st, lw ? 1 : 0, fdrec, rf, mpk);
@@ -4537,7 +4849,7 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
                 hipLaunchKernelGGL(ward_interleave_kernel, dim3((unsigned)icl_ceil_div((WB_K / 2) * w->cn_stride, 256)), dim3(256), 0, ctx->stream, w->cnew,
                                    w->cn_stride, w->cnewI, w->st);
         };
-        const unsigned lb_blocks = (unsigned)icl_ceil_div(w->S, WL_SLOTS) + 2 + WB_R;
+        const unsigned lb_blocks = (unsigned)icl_ceil_div(w->M, WL_SLOTS) + 2 + WB_R; // (one lane per creation id)
         auto update_b = [&]() {
             if (lbm) {
                 hipLaunchKernelGGL(ward_update_lb_kernel, dim3(lb_blocks), dim3(WL_THREADS), 0, ctx->stream, w->S, w->slot_id, w->asz, w->rowoff, w->mcol, w->msz,
