@@ -413,6 +413,33 @@ __device__ __forceinline__ void block_argmin(float &v, int &i, float *sv, int *s
     __syncthreads();
 }
 
+// Exclusion lists of the row scans (the members of the tentative batch).  A list of nex > 0 ids is FOLLOWED by a 2 048-bit filter
+// (WEX_WORDS words: bit id & 2047 set for every listed id): one LDS read rules out almost every candidate, the list itself is walked only
+// behind a set bit.  (With the list alone -- 32 reads per candidate that beat a thread's best, 64 with 32 picks per step -- the first groups
+// of a scan, where every group beats the best so far, cost a merged row's re-scan a quarter of its time.)  nex == 0: no list, no filter.
+#define WEX_WORDS 64
+// (out of line, not unrolled: inlined, hipcc loads the whole list into registers AHEAD of the scan loops and keeps it there --
+// 64 VGPRs per inlined scan at 32 picks per step, 4 256 spilled registers in ward_update_lb_kernel)
+__device__ __attribute__((noinline)) bool wex_list_hit(const int *ex, int nex, int c)
+{
+    bool hit = false;
+#pragma unroll 1
+    for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
+    return hit;
+}
+__device__ __forceinline__ bool wex_hit(const int *ex, int nex, int c)
+{
+    if (nex <= 0) return false;
+    if (!((ex[nex + ((c >> 5) & (WEX_WORDS - 1))] >> (c & 31)) & 1)) return false;
+    return wex_list_hit(ex, nex, c);
+}
+// fills list + filter from the batch in the state (called by the first 2 K threads of a workgroup after `fl` was zeroed; barrier afterwards)
+__device__ __forceinline__ void wex_add(int *ex, int nex, int slot, int id)
+{
+    ex[slot] = id;
+    if (id >= 0) atomicOr(reinterpret_cast<unsigned *>(&ex[nex + ((id >> 5) & (WEX_WORDS - 1))]), 1u << (id & 31));
+}
+
 // Scans row r (len = number of candidate columns 0..len-1).  asz == nullptr: no mask (dense API matrix).
 __device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t len, const int32_t *__restrict__ asz,
                                          int my_size, int max_size, float &bv, int &bi)
@@ -477,9 +504,7 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
     bi = -1;
     auto visit = [&](float v, int m, int c) {
         if (m > 0 && m + my_size <= max_size && c < my_id && (v < bv || (v == bv && c < bi))) {
-            bool ex_hit = false; // (the list is read where it lives -- LDS -- on the rare candidates only: no registers held across the row)
-            for (int z = 0; z < nex; ++z) ex_hit |= ex[z] == c;
-            if (!ex_hit) {
+            if (!wex_hit(ex, nex, c)) { // (the list is read where it lives -- LDS -- on the rare candidates only: no registers held across the row)
                 bv = v;
                 bi = c;
             }
@@ -500,11 +525,7 @@ __device__ __forceinline__ void scan_row_m(const float *__restrict__ row, int64_
             const bool ok = (m > 0) & (m + my_size <= max_size) & (c < my_id);
             return ((unsigned long long)(ok ? __float_as_uint(v) : 0xffffffffu) << 32) | (unsigned)c;
         };
-        auto is_ex = [&](int c) {
-            bool hit = false;
-            for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
-            return hit;
-        };
+        auto is_ex = [&](int c) { return wex_hit(ex, nex, c); };
         for (int64_t q0 = threadIdx.x; q0 < nvec; q0 += WB_SCAN_U * (int64_t)blockDim.x) {
             float4 v[WB_SCAN_U];
             uint4 k[WB_SCAN_U];
@@ -862,11 +883,7 @@ __device__ __forceinline__ void scan_row_refine(float *__restrict__ row, int64_t
     // (tv0, ti0, thr0): the caller's pass has already found the best value and a threshold: the first round skips pass A
     __shared__ int ref_cnt;
     __shared__ int ref_col[WB_REF_CAP];
-    auto excluded = [&](int c) { // (read from the caller's list -- LDS -- on the rare candidates only: no registers held across the row)
-        bool hit = false;
-        for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
-        return hit;
-    };
+    auto excluded = [&](int c) { return wex_hit(ex, nex, c); }; // (read from the caller's list -- LDS -- on the rare candidates only: no registers held across the row)
     const float nme = my_id < rf.n ? rf.nrm[my_id] : 0.0f;
     for (bool first = true;; first = false) {
         // pass A: the first minimum among VALUES, the smallest upper bound among flagged entries
@@ -1104,11 +1121,7 @@ __device__ __forceinline__ void scan_row_min(float *__restrict__ row, int64_t le
         })
         return;
     }
-    auto excluded = [&](int c) {
-        bool hit = false;
-        for (int z = 0; z < nex; ++z) hit |= ex[z] == c;
-        return hit;
-    };
+    auto excluded = [&](int c) { return wex_hit(ex, nex, c); };
     float tv = ICL_MAXF, lv = ICL_MAXF, lv2 = ICL_MAXF; // lv2: the second smallest lower bound (an excluded entry may count: it only errs low)
     int ti = -1, lc = -1;
     if (mpk) {
@@ -1952,12 +1965,13 @@ __device__ __forceinline__ void wave_pop_top(unsigned long long k1, unsigned lon
 // Phase B (after all slices are published): the matched rows are dealt round-robin in slice order; workgroup wg takes
 // entries wg, wg + WB_R, ... (WB_RM of them), re-minimises each without the batch's members and publishes the result.
 // The finish kernel installs them if the whole batch commits; the preselection waits for the ones it needs.
+template <int K>
 __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_t *__restrict__ asz, const float *__restrict__ rowmin,
                                  const int32_t *__restrict__ rownn, float *__restrict__ Dtri, const int64_t *__restrict__ rowoff,
                                  const int32_t *__restrict__ msz, const int32_t *__restrict__ mcid,
                                  int max_size, ward_state *__restrict__ st, float *sv, int *si, const wrefine &rf, const uint32_t *__restrict__ mpk = nullptr)
 {
-    __shared__ int excl[2 * WB_K];
+    __shared__ int excl[2 * K + WEX_WORDS]; // the members of the tentative batch, then their filter (wex_hit)
     __shared__ int lcnt;
     __shared__ int lrows[WB_PA_CAP];
     __shared__ int mine[WB_RM];
@@ -1968,15 +1982,16 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     if (st->done) return;
     const int nb = st->B.nb, t0 = st->t, epoch = st->B.epoch;
     if (nb <= 0 || t0 + nb >= st->target) return;
-    if (threadIdx.x < 2 * WB_K) {
-        const int j = threadIdx.x >> 1;
-        excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
-    }
+    if (threadIdx.x < WEX_WORDS) excl[2 * K + threadIdx.x] = 0;
     if (threadIdx.x == 0) lcnt = 0;
     __syncthreads();
-    int ex[2 * WB_K]; // wave-uniform: kept in scalar registers (every row-cache entry is tested against all of them)
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = __builtin_amdgcn_readfirstlane(excl[z]);
+    if (threadIdx.x < 2 * K) {
+        const int j = threadIdx.x >> 1;
+        wex_add(excl, 2 * K, threadIdx.x, j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1);
+    }
+    __syncthreads();
+    // (membership in the batch: the list's filter answers with one LDS read; until round 4 the 2 K ids sat in scalar registers and every
+    // row-cache entry was compared with all of them -- 64 registers at 32 picks per step)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     WB_TIMER(const unsigned long long ta0 = wall_clock64();)
     // ---- phase A: one pass over this workgroup's slice (int4 groups of rownn / float4 groups of rowmin)
@@ -1994,14 +2009,8 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         for (int e = 0; e < 4; ++e) {
             if (!(vv[e] < ICL_MAXF)) continue; // dead rows and rows being created hold MaxFloat32
             const int r = (int)(q * 4 + e);
-            bool self = false, dep = false;
-#pragma unroll
-            for (int z = 0; z < 2 * WB_K; ++z) {
-                self |= r == ex[z];
-                dep |= (nnv[e] >= 0) & (nnv[e] == ex[z]);
-            }
-            dep |= nnv[e] == WB_NN_BOUND; // (lb mode) a row that has never been scanned: made exact one step after its creation
-            if (self) continue; // the batch's own members are dead if it commits
+            if (wex_hit(excl, 2 * K, r)) continue; // the batch's own members are dead if it commits
+            const bool dep = !WB_LAZY_TOP && ((nnv[e] >= 0 && wex_hit(excl, 2 * K, nnv[e])) || nnv[e] == WB_NN_BOUND);
             if (!WB_LAZY_TOP && dep) {
                 const int at = atomicAdd(&lcnt, 1);
                 if (at < WB_PA_CAP) lrows[at] = r; // beyond the cap: left to the lazy path (exact, just later)
@@ -2047,9 +2056,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
                 if (nn == WB_NN_BOUND)
                     stale = true;
                 else if (nn >= 0) {
-                    stale = asz[nn] <= 0;
-#pragma unroll
-                    for (int z = 0; z < 2 * WB_K; ++z) stale |= nn == ex[z];
+                    stale = asz[nn] <= 0 || wex_hit(excl, 2 * K, nn);
                 }
             }
             const unsigned long long sm = __ballot(stale);
@@ -2105,7 +2112,7 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
         int ri = -1;
         if (r >= 0) {
             WB_TIMER(const unsigned long long tr0 = wall_clock64();)
-            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * WB_K, rv, ri, sv, si, rf, sv + 1024, mpk);
+            scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, 2 * K, rv, ri, sv, si, rf, sv + 1024, mpk);
             WB_TIMER(if (threadIdx.x == 0) {
                 const unsigned long long dt = wall_clock64() - tr0;
                 atomicAdd(&st->B.dbg6[r < n ? 2 : 4], dt);   /* time in rescans: singleton rows / merged rows */
@@ -2124,12 +2131,13 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     }
 }
 
+template <int K>
 __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *__restrict__ asz, float *__restrict__ rowmin, int32_t *__restrict__ rownn,
                                      float *__restrict__ Dtri, const int64_t *__restrict__ rowoff, const int32_t *__restrict__ msz,
                                      const int32_t *__restrict__ mcid, int max_size,
                                      ward_state *__restrict__ st, float *sv, int *si, int *sh, const wrefine &rf, const uint32_t *__restrict__ mpk = nullptr)
 {
-    __shared__ int excl[2 * WB_K];
+    __shared__ int excl[2 * K + WEX_WORDS]; // the members of the tentative batch, then their filter (wex_hit)
     __shared__ unsigned long long wstream[16 * (WB_WTOP + 1)];
     __shared__ int cmd[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2144,14 +2152,15 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         }
         return;
     }
-    if (threadIdx.x < 2 * WB_K) {
+    if (threadIdx.x < WEX_WORDS) excl[2 * K + threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 2 * K) {
         const int j = threadIdx.x >> 1;
-        excl[threadIdx.x] = j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1;
+        wex_add(excl, 2 * K, threadIdx.x, j < nb ? ((threadIdx.x & 1) ? st->B.b[j] : st->B.a[j]) : -1);
     }
     __syncthreads();
-    int ex[2 * WB_K];
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) ex[z] = __builtin_amdgcn_readfirstlane(excl[z]);
+    static_assert(2 * K <= 64, "the members of the batch and of the picks made here: one per lane of wave 0");
+    const int myex = (int)(threadIdx.x & 63) < 2 * K ? excl[threadIdx.x & 63] : -1; // lane z: member z of the tentative batch
     // ---- the row caches were scanned by the spare workgroups (one slice each): merge their WB_R streams of WB_PA_KEYS entries
     const int epoch0 = st->B.epoch;
     if (wave == 0) {
@@ -2209,13 +2218,11 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         spl_nn[m] = -1;
         spl_val[m] = ICL_MAXF;
     }
-    int pm[2 * WB_K]; // members of the picks made here
-#pragma unroll
-    for (int z = 0; z < 2 * WB_K; ++z) pm[z] = -1;
+    int mypm = -1; // lane 2 i / 2 i + 1: the members of pick i made here
     for (;;) {
         if (wave == 0) {
             int action = 0, arow = -1, alane = -1; // 0 stop, 2 rescan + write back, 3 speculative rescan (override)
-            while (npick < WB_K && t_after + npick < target) {
+            while (npick < K && t_after + npick < target) {
                 const unsigned long long m = wave_min_u64(key);
                 if (m == ~0ull || (m & 1ull)) break; // exhausted / coverage ends
                 const int src = __ffsll((long long)__ballot(key == m)) - 1;
@@ -2234,12 +2241,8 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                 }
                 // a stale row (partner dead, or never scanned: WB_NN_BOUND): the spare workgroups have re-minimised it without the batch's members, like a
                 // row whose partner is in the batch
-                bool in_batch = rn == WB_NN_BOUND || (WB_LAZY_TOP && !ralive), in_picks = false;
-#pragma unroll
-                for (int z = 0; z < 2 * WB_K; ++z) {
-                    in_batch |= ex[z] == rn;
-                    in_picks |= (pm[z] == rn) | (pm[z] == r);
-                }
+                const bool in_batch = rn == WB_NN_BOUND || (WB_LAZY_TOP && !ralive) || __any(myex == rn);
+                const bool in_picks = __any((mypm == rn) | (mypm == r));
                 if (in_picks) break; // shares a cluster with an earlier pick: the prefix ends here
                 if (in_batch) {      // partner dies if the batch commits: re-minimise without the batch's members
                     if (spl_n < 0) { // the spare workgroups' results (they run ahead of this workgroup in the grid)
@@ -2308,16 +2311,12 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                     st->B.pre_sa[npick] = s_r;
                     st->B.pre_sb[npick] = s_n;
                 }
-#pragma unroll
-                for (int z = 0; z < WB_K; ++z)
-                    if (z == npick) {
-                        pm[2 * z] = r;
-                        pm[2 * z + 1] = rn;
-                    }
+                if (lane == 2 * npick) mypm = r;
+                if (lane == 2 * npick + 1) mypm = rn;
                 ++npick;
                 if (lane == src) key = ~0ull;
             }
-            if (action && nresc >= 3 * WB_K) action = 0; // bound the work of one step
+            if (action && nresc >= 3 * K) action = 0; // bound the work of one step
             if (lane == 0) {
                 cmd[0] = action;
                 cmd[1] = arow;
@@ -2330,7 +2329,7 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
         ++nresc;
         float rv;
         int ri;
-        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * WB_K : 0, rv, ri, sv, si, rf, sv + 1024, mpk); // ends with a barrier: cmd may be rewritten afterwards
+        scan_row_min(Dtri + rowoff[r], ward_row_len(r, n), msz, mcid, r, asz[r], max_size, excl, action == 3 ? 2 * K : 0, rv, ri, sv, si, rf, sv + 1024, mpk); // ends with a barrier: cmd may be rewritten afterwards
         if (wave == 0) {
             if (lane == alane) {
                 if (ri < 0) {
@@ -2586,7 +2585,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
     if (blockIdx.x < WB_R) {
         float *sv = reinterpret_cast<float *>(wb_lds);
         int *si = reinterpret_cast<int *>(sv + 16);
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
+        ward_spec_rescan<WB_K>((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg5[0], wall_clock64());)
         return;
     }
@@ -2596,7 +2595,7 @@ __global__ __launch_bounds__(WX_THREADS, 3) void ward_update_batch2_kernel(int d
         int *sh = si + 16;
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
+        ward_preselect_batch<WB_K>(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -2960,12 +2959,12 @@ __global__ __launch_bounds__(WB_THREADS) void ward_update_batch_lw_kernel(int64_
     __shared__ int sh[8];
     if (blockIdx.x < WB_R) {
         const wrefine norf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f}; // FAST mode: the MFMA matrix holds (approximate) values
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, norf);
+        ward_spec_rescan<WB_K>((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, norf);
         return;
     }
     if (blockIdx.x == WB_R) {
         const wrefine norf{nullptr, nullptr, 0, 0, 0.0f, 0.0f, nullptr, 0.0f};
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, norf);
+        ward_preselect_batch<WB_K>(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, norf);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -3147,7 +3146,9 @@ __global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__res
 #define WL_THREADS 768
 #endif
 #define WL_SLOTS 256 /* creation ids per main workgroup of ward_update_lb_kernel */
-#define WL_K 16      /* picks per step of the bound-rows loop */
+#ifndef WL_K
+#define WL_K 32      /* picks per step of the bound-rows loop (the exact-rows loop: WB_K) */
+#endif
 // update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
 // the pairs of clusters created by this batch, then one lane per live cluster.
 __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, const int32_t *__restrict__ slot_id, const int32_t *__restrict__ asz,
@@ -3162,14 +3163,14 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     int *si = reinterpret_cast<int *>(sv + 16);
     int *sh = si + 16;
     if (blockIdx.x < WB_R) {
-        ward_spec_rescan((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
+        ward_spec_rescan<WL_K>((int)blockIdx.x, n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) atomicMax(&st->B.dbg5[0], wall_clock64());)
         return;
     }
     if (blockIdx.x == WB_R) {
         WB_TIMER(const unsigned long long t0 = wall_clock64();)
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg_t0 = t0;)
-        ward_preselect_batch(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
+        ward_preselect_batch<WL_K>(n, asz, rowmin, rownn, Dtri, rowoff, msz, mcid, max_size, st, sv, si, sh, rf, mpk);
         WB_TIMER(if (threadIdx.x == 0) st->B.dbg[0] += wall_clock64() - t0;)
         return;
     }
@@ -3179,11 +3180,11 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     const int done = st->done, nb = st->B.nb, nlive = st->nlive, t = st->t;
     if (done || nb <= 0) return;
     const float g1 = st->lb_g1, delta2 = st->lb_delta2;
-    __shared__ int pa[WB_K], pb[WB_K], psa[WB_K], psb[WB_K], mca[WB_K], mcb[WB_K];
-    __shared__ float pv[WB_K];
-    __shared__ int64_t roa[WB_K], rob[WB_K], ron[WB_K];
-    __shared__ unsigned long long wk[WL_THREADS / 64][WB_K][2];
-    if (threadIdx.x < WB_K) {
+    __shared__ int pa[WL_K], pb[WL_K], psa[WL_K], psb[WL_K], mca[WL_K], mcb[WL_K];
+    __shared__ float pv[WL_K];
+    __shared__ int64_t roa[WL_K], rob[WL_K], ron[WL_K];
+    __shared__ unsigned long long wk[WL_THREADS / 64][WL_K][2];
+    if (threadIdx.x < WL_K) {
         const int j = threadIdx.x;
         const bool on = j < nb;
         const int a = on ? st->B.a[j] : -1, b = on ? st->B.b[j] : -1;
@@ -3203,7 +3204,8 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     // lower bound of the value, an unflagged one the value itself
     if (blockIdx.x == WB_R + 1) {
         // clusters created by this batch against each other: thread (i, j), i < j < nb, bounds D(c_j, c_i) by nesting the recurrence
-        const int vi = (int)threadIdx.x / WB_K, vj = (int)threadIdx.x % WB_K;
+        for (int pr = (int)threadIdx.x; pr < WL_K * WL_K; pr += WL_THREADS) {
+        const int vi = pr / WL_K, vj = pr % WL_K;
         if (vi < vj && vj < nb) {
             const int ai = pa[vi], bi = pb[vi], sai = psa[vi], sbi = psb[vi], aj = pa[vj], bj = pb[vj];
             const int sci = sai + sbi, scj = psa[vj] + psb[vj];
@@ -3218,6 +3220,7 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
                 atomicMin(&st->B.ckey[vj], key);
                 atomicMin(&st->B.ckey2[vj], key); // a cluster created by this batch survives it
             }
+        }
         }
         return;
     }
@@ -3234,12 +3237,12 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
     const bool live = x >= 0 && sx > 0;
     const int64_t rx = live ? rowoff[x] : 0;
     const int cx = live ? mcol[x] : 0;
-    int jm = WB_K; // the pick x is a member of (WB_K: none): x is gone when c_jm is created, alive for the rows before it
+    int jm = WL_K; // the pick x is a member of (WL_K: none): x is gone when c_jm is created, alive for the rows before it
 #pragma unroll
-    for (int j = WB_K - 1; j >= 0; --j)
+    for (int j = WL_K - 1; j >= 0; --j)
         if (j < nb && (x == pa[j] || x == pb[j])) jm = j;
-    const bool survives = live && jm == WB_K;
-    constexpr int NJ = (WB_K + NG - 1) / NG;
+    const bool survives = live && jm == WL_K;
+    constexpr int NJ = (WL_K + NG - 1) / NG;
     float la[NJ], lbv[NJ];
 #pragma unroll
     for (int q = 0; q < NJ; ++q) { // all reads of the thread in flight together
@@ -3251,7 +3254,7 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
             lbv[q] = Dtri[pb[j] > x ? rob[j] + cx : rx + mcb[j]];
         }
     }
-    for (int q = lane; q < WB_K * 2; q += 64) wk[wave][q >> 1][q & 1] = ~0ull; // (this wave's own entries; it fills the picks of its group below)
+    for (int q = lane; q < WL_K * 2; q += 64) wk[wave][q >> 1][q & 1] = ~0ull; // (this wave's own entries; it fills the picks of its group below)
 #pragma unroll
     for (int q = 0; q < NJ; ++q) {
         const int j = sub + q * NG;
@@ -3264,14 +3267,14 @@ __global__ __launch_bounds__(WL_THREADS) void ward_update_lb_kernel(int64_t S, c
         }
         key = wave_umin64(key);
         key2 = wave_umin64(key2);
-        if (lane == 0 && j < WB_K) {
+        if (lane == 0 && j < WL_K) {
             wk[wave][j][0] = key;
             wk[wave][j][1] = key2;
         }
     }
     WB_TIMER(if (threadIdx.x == 0 && blockIdx.x == WB_R + 2) st->B.dbg[2] += wall_clock64() - tm0;) // "virt" column of the print: main block 0 up to its rows' stores
     __syncthreads();
-    if (threadIdx.x < 2 * WB_K) { // one atomic per workgroup, row and key
+    if (threadIdx.x < 2 * WL_K) { // one atomic per workgroup, row and key
         const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
         unsigned long long k = ~0ull;
         for (int w = 0; w < WL_THREADS / 64; ++w) k = wk[w][j][which] < k ? wk[w][j][which] : k;
