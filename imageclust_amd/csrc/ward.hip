@@ -1095,6 +1095,7 @@ __device__ __forceinline__ void block_argmin2b(float &v0, int &i0, float &v1, in
 }
 
 #ifdef ICL_WARD_TIMERS
+__device__ unsigned long long g_walk_dbg[8]; // why the preselection's walk ended: [0] streams exhausted, [1] a sentinel, [2] the row of a picked member, [3] partner is a picked member, [4] override list full
 __device__ unsigned long long g_scan_dbg[8]; // plain row scans: [0] time in the load/visit loop, [1] in the reduce, [2] scans, [3] columns
 #endif
 // The row scan of every merge-loop kernel: result reduced over the workgroup.
@@ -1996,11 +1997,17 @@ __device__ __forceinline__ void ward_spec_rescan(int wg, int64_t n, const int32_
     WB_TIMER(const unsigned long long ta0 = wall_clock64();)
     // ---- phase A: one pass over this workgroup's slice (int4 groups of rownn / float4 groups of rowmin)
     const int64_t nvec = (n + t0 + 3) >> 2; // rows being created hold MaxFloat32 / -1
-    const int64_t per = (nvec + WB_R - 1) / WB_R;
-    const int64_t q_lo = (int64_t)wg * per, q_hi = (q_lo + per < nvec ? q_lo + per : nvec);
+    // Slice wg = the 64-byte chunks (16 rows) c == wg (mod WB_R) of the row caches.  (Contiguous runs until round 4: the youngest clusters -- the
+    // end of the arrays -- are the likeliest candidates, so a few slices held most of the head of the candidate list and their sentinels, the sixth
+    // key of a slice, ended the preselection's walk after ~20 picks.)
+    const int64_t nchunk = (nvec + 3) >> 2;
     unsigned long long k1 = ~0ull, k2 = ~0ull;
     int nseen = 0;
-    for (int64_t q = q_lo + threadIdx.x; q < q_hi; q += blockDim.x) {
+    for (int64_t pp = threadIdx.x;; pp += blockDim.x) {
+        const int64_t ch = (int64_t)wg + (int64_t)WB_R * (pp >> 2);
+        if (ch >= nchunk) break;
+        const int64_t q = ch * 4 + (pp & 3);
+        if (q >= nvec) continue;
         const int4 nn4 = reinterpret_cast<const int4 *>(rownn)[q];
         const float4 v4 = reinterpret_cast<const float4 *>(rowmin)[q];
         const int nnv[4] = {nn4.x, nn4.y, nn4.z, nn4.w};
@@ -2224,7 +2231,10 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
             int action = 0, arow = -1, alane = -1; // 0 stop, 2 rescan + write back, 3 speculative rescan (override)
             while (npick < K && t_after + npick < target) {
                 const unsigned long long m = wave_min_u64(key);
-                if (m == ~0ull || (m & 1ull)) break; // exhausted / coverage ends
+                if (m == ~0ull || (m & 1ull)) { // exhausted / coverage ends
+                    WB_TIMER(if (lane == 0) atomicAdd(&g_walk_dbg[m == ~0ull ? 0 : 1], 1ull);)
+                    break;
+                }
                 const int src = __ffsll((long long)__ballot(key == m)) - 1;
                 const int r = (int)((m & 0xffffffffull) >> 1);
                 const int rn = __shfl(nn, src, 64);
@@ -2243,7 +2253,10 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                 // row whose partner is in the batch
                 const bool in_batch = rn == WB_NN_BOUND || (WB_LAZY_TOP && !ralive) || __any(myex == rn);
                 const bool in_picks = __any((mypm == rn) | (mypm == r));
-                if (in_picks) break; // shares a cluster with an earlier pick: the prefix ends here
+                if (in_picks) { // shares a cluster with an earlier pick: the prefix ends here
+                    WB_TIMER(if (lane == 0) atomicAdd(&g_walk_dbg[__any(mypm == r) ? 2 : 3], 1ull);)
+                    break;
+                }
                 if (in_batch) {      // partner dies if the batch commits: re-minimise without the batch's members
                     if (spl_n < 0) { // the spare workgroups' results (they run ahead of this workgroup in the grid)
                         int ok = lane >= WB_R;
@@ -2295,7 +2308,10 @@ __device__ __forceinline__ void ward_preselect_batch(int64_t n, const int32_t *_
                         alane = src;
                         break;
                     }
-                    if (nov >= WB_MAXOV) break;
+                    if (nov >= WB_MAXOV) {
+                        WB_TIMER(if (lane == 0) atomicAdd(&g_walk_dbg[4], 1ull);)
+                        break;
+                    }
                     action = 3;
                     arow = r;
                     alane = src;
@@ -5006,6 +5022,13 @@ static int cluster_locked(icl_ctx *ctx, const float *d_E, int64_t n, int32_t d, 
         (void)hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_scan_dbg), sizeof(gs));
         unsigned long long zero[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), zero, sizeof(zero));
+        {
+            unsigned long long gw[8] = {0}, z8[8] = {0};
+            (void)hipMemcpyFromSymbol(gw, HIP_SYMBOL(g_walk_dbg), sizeof(gw));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_dbg), z8, sizeof(z8));
+            fprintf(stderr, "[icl] the preselection's walk ended (of %d steps): streams exhausted %llu, at a sentinel %llu, at the row of a picked member %llu, at a row whose partner was picked %llu, override list full %llu\n",
+                    hst.B.steps, gw[0], gw[1], gw[2], gw[3], gw[4]);
+        }
         fprintf(stderr, "[icl] spare workgroup 0, phase A per step us: slice loop %.1f, wave pops %.1f, merge + stale look-ups %.1f, fence + flag %.1f\n", gs[4] * 0.01 / hst.B.steps,
                 gs[5] * 0.01 / hst.B.steps, gs[6] * 0.01 / hst.B.steps, gs[7] * 0.01 / hst.B.steps);
         fprintf(stderr, "[icl] plain row scans: %llu, %.0f columns each, %.1f us in the load/visit loop, %.1f us in the reduce; per step us: first main start -> last main end %.1f, preselection start -> first main start %.1f, last main end -> finish start %.1f\n",
