@@ -3163,7 +3163,8 @@ __global__ __launch_bounds__(1024) void ward_lb_consts_kernel(const float *__res
 #endif
 #define WL_SLOTS 256 /* creation ids per main workgroup of ward_update_lb_kernel */
 #ifndef WL_K
-#define WL_K 32      /* picks per step of the bound-rows loop (the exact-rows loop: WB_K) */
+#define WL_K 24      /* picks per step of the bound-rows loop (the exact-rows loop: WB_K); a multiple of 8, <= 32.  Merge loop at N = 100 000 with the slices interleaved:
+                        16 picks 559 ms (5 609 steps), 24 picks 486 ms (3 780 steps), 32 picks 496 ms (2 905 steps: 67 stale rows per step for 64 spare workgroups) */
 #endif
 // update(t) of lb mode: grid = [0, WB_R) spare row re-minimisers, WB_R the preselection (both as in ward_update_batch2_kernel), WB_R + 1
 // the pairs of clusters created by this batch, then one lane per live cluster.
