@@ -397,7 +397,7 @@ def main():
                 ward_roof.pop("valu", None)
                 ward_roof["algorithmic_unit"] = ("12 bytes per (new row, live cluster): two stored entries read, one lower bound written -- the Lance-Williams "
                                                  "recurrence on the distance matrix instead of 3*D operations on the centroids (SURVEY.md 8d's 4*n*D per merge no longer "
-                                                 "moves); the bytes of the row re-scans that ride in the same launch (8 bytes x N columns each, ~35 per launch) are not counted; `traffic` "
+                                                 "moves); the bytes of the row re-scans that ride in the same launch (8 bytes x N columns each, ~50 per launch) are not counted; `traffic` "
                                                  "(PMC) is ~17x the algorithmic bytes: one of the two read directions walks a COLUMN of the 40 GB matrix, 4 useful bytes per 64-byte line")
                 ward_roof["note"] = ("the launch is bound by LATENCY, not by HBM or the vector ALUs: its length is the chain phase A (row-cache slices) -> flag barrier "
                                      "-> one or two row re-scans + one exact evaluation (a chain of D dependent fp32 additions) per spare workgroup -> preselection; "
